@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — SPH throughput of the MI355X stepper on the BASELINE.json workloads.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg0|cfg4] [--no-cpu]
+
+A "step" is one pass of the hot path (kick/drift + counting sort + density/EOS + force/kick,
+pi_sph_fluid.c:612-641) over every fluid particle of the scene.  Inputs are resident in HBM when
+the timed region starts (sph_create has run); the timed region is exactly K steps, bracketed by a
+device synchronisation (and a barrier across ranks when N > 1), MAX over ranks.
+
+Workload at N = 1: cfg2, the 2 000 000-particle dam break (4000 x 500 block, box 1200 x 60 m), the
+configuration BASELINE.json's north_star quotes its single-GPU target and roofline on.  At N > 1 the
+same scene is extended to N slabs of 2M particles (cfg3 = the N = 4 member of that family), i.e.
+weak scaling; `value` is the whole-job Mparticle-steps/s.  cfg1 (the 262 144-particle drop) is also
+measured at N = 1 and reported under "also".
+
+One JSON line on stdout (rank 0).  Everything the oracle touches is the cpu_baseline leg only.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md "HBM3E peak BW"); ~6290 GB/s measured copy
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def run_single(sph, name, steps, warmup, profile_steps=20):
+    """K timed steps of one scene on device 0; returns a result dict."""
+    prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
+    n = len(f)
+    t0 = time.time()
+    ctx = sph.Context(prm, f, b, 0.0, -9.81, device=0)
+    create_s = time.time() - t0
+    ctx.step(warmup, 0.0, -9.81)
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.step(steps, 0.0, -9.81)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    kt = ctx.profile_steps(profile_steps, 0.0, -9.81)      # HIP events on the kernels' own stream
+    ctx.sync()
+    max_rho, max_speed = ctx.stats()
+    rows, cols = ctx.grid_dims()
+    res = {"workload": name, "n_fluid": n, "n_boundary": len(b), "grid_cells": rows * cols,
+           "steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
+           "mparticle_steps_per_s": steps / dt * n / 1e6, "kernel_ms": kt,
+           "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s,
+           "device_mb": ctx.device_bytes() / 1e6}
+    ctx.close()
+    return res
+
+
+def roofline(sph, res):
+    """HBM roofline of the dominant kernel: algorithmic bytes per launch / its mean launch duration."""
+    kt = res["kernel_ms"]
+    cand = {k: kt[k] for k in ("kick_drift_key", "reorder", "density_eos", "force_kick")}
+    dom = max(cand, key=cand.get)
+    algo = sph.KERNEL_ALGO_BYTES[dom] * res["n_fluid"]
+    achieved = algo / (kt[dom] * 1e-3) / 1e9
+    step_bytes = sph.STEP_ALGO_BYTES * res["n_fluid"]
+    step_gbs = step_bytes * res["steps_per_s"] / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):          # PMC passes are collected offline with rocprofv3 (see profiles/README.md)
+        try:
+            traffic = json.load(open(tpath)).get(res["workload"], {}).get(dom)
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algo_bytes_per_launch": algo, "kernel_ms": round(kt[dom], 5),
+            "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+            "step_algo_bytes": step_bytes}
+
+
+def cpu_baseline(sph, name, nsteps=8, warm=2):
+    """The oracle (CPU restatement of the reference, reference flags -Ofast -march=native -fopenmp) timed
+    on this host's cores on the same scene: the 'port' baseline (the reference itself cannot run
+    > 65 534 particles: unsigned short indices, pi_sph_fluid.c:78-79)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liborc_fast.so"])   # -march=native of THIS host
+    O = orc.Oracle("fast")
+    prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
+    p = O.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
+    of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()
+    threads = os.cpu_count() or 1
+    O.psi(p, ob)
+    du, dv = O.eval(p, of, ob, 0.0, -9.81, threads=threads)
+    O.steps(p, of, ob, 0.0, -9.81, du, dv, warm, threads=threads)
+    t0 = time.perf_counter()
+    O.steps(p, of, ob, 0.0, -9.81, du, dv, nsteps, threads=threads)
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(nsteps / dt * len(f) / 1e6, 3), "unit": "Mparticle-steps/s",
+            "timesteps_per_s": round(nsteps / dt, 4), "cores": threads, "kind": "port",
+            "sample": "%d steps (after %d warm-up) of the full %s scene, %d fluid particles, %d OpenMP threads, %s"
+                      % (nsteps, warm, name, len(f), threads, model)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary cfg1 measurement")
+    args = ap.parse_args()
+
+    sph = importlib.import_module("pi-sph-fluid_amd")
+    if not (os.path.exists(sph.LIB_HIP) and os.path.exists(sph.LIB_HOST)):
+        sph.build()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from bench_slab import run_slabs          # one process per GPU over RCCL (torch.distributed)
+        run_slabs(sph, args)
+        return
+
+    res = run_single(sph, args.workload, args.steps, args.warmup)
+    log("primary:", json.dumps(res))
+    out = {
+        "metric": "SPH Mparticle-steps/sec (N_fluid x timesteps/sec / 1e6)",
+        "value": round(res["mparticle_steps_per_s"], 2),
+        "unit": "Mparticle-steps/s",
+        "timesteps_per_s": round(res["steps_per_s"], 2),
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(res["ms_per_step"], 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d fluid + %d boundary particles, dam break, box %s" %
+                   (res["workload"], res["n_fluid"], res["n_boundary"],
+                    "1200 x 60 m" if res["workload"] == "cfg2" else "see SURVEY.md 8d"),
+                   "n_fluid": res["n_fluid"], "n_boundary": res["n_boundary"], "grid_cells": res["grid_cells"],
+                   "parallelism": "1 GPU"},
+        "kernel_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items()},
+        "roofline": roofline(sph, res),
+    }
+    if not args.no_also and args.workload != "cfg1":
+        r1 = run_single(sph, "cfg1", max(args.steps, 1), args.warmup)
+        log("also:", json.dumps(r1))
+        out["also"] = [{"workload": "cfg1: %d fluid + %d boundary, drop on dry surface, box 409.6 x 204.8 m" %
+                        (r1["n_fluid"], r1["n_boundary"]),
+                        "value": round(r1["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
+                        "timesteps_per_s": round(r1["steps_per_s"], 2), "ms_per_step": round(r1["ms_per_step"], 5),
+                        "kernel_ms": {k: round(v, 5) for k, v in r1["kernel_ms"].items()},
+                        "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r1["n_fluid"] * r1["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)}]
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(sph, args.workload)
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

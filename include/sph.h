@@ -1,0 +1,151 @@
+/* sph.h — C ABI of the MI355X-native 2-D WCSPH stepper (libsph_hip.so).
+ *
+ * This is the drop-in boundary for the per-step compute of
+ * colonelwatch/pi-sph-fluid.  The reference has no FFI seam: main() owns raw
+ * arrays and calls the physics functions directly.  Each entry point below
+ * names the reference call site(s) it replaces (file = pi_sph_fluid.c).
+ * Plain C types only; no HIP, torch or C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every function returning int returns SPH_OK (0) or a negative sph_error;
+ *     sph_last_error() gives the text of the last failure of that context
+ *     (reference convention is exit(1) :419-422, printf warnings :546-547, or UB)
+ *   - the library owns all device memory; the caller owns every buffer it
+ *     passes in or receives results in (reference: bare malloc'd arrays, :491-493)
+ *   - one sph_ctx is driven by one host thread at a time (reference: all
+ *     threads of the omp team enter the physics functions, :610, :630-632)
+ *   - work is enqueued on the context's HIP stream; sph_step() returns without
+ *     waiting, read-backs and sph_sync() wait
+ *   - there is NO CPU fallback: without a usable MI355X every compute entry
+ *     point fails with SPH_E_HIP
+ */
+#ifndef SPH_H
+#define SPH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_ABI_VERSION 1
+
+typedef enum sph_error {
+    SPH_OK = 0,
+    SPH_E_ARG = -1,            /* bad argument (NULL, negative count, non-uniform fluid mass, ...) */
+    SPH_E_HIP = -2,            /* HIP runtime failure or no gfx950 device */
+    SPH_E_OUT_OF_DOMAIN = -3,  /* particles left [x_min,x_max]x[y_min,y_max]; they were clamped into edge cells (reference: heap overflow, :111-116) */
+    SPH_E_NAN = -4,            /* a particle position became NaN/Inf */
+    SPH_E_NOMEM = -5,
+    SPH_E_CAPACITY = -6,       /* slab mode: local particle or halo capacity exceeded */
+    SPH_E_STATE = -7           /* call not valid in the context's current state */
+} sph_error;
+
+/* byte-compatible with the reference's `struct particle` (:26-31): 7 x f32, 28 B, no padding.
+ * fluid: m = RHO_0*V (:502); boundary: m holds the Akinci pseudo-mass psi (:259), rho = RHO_0 (:526). */
+typedef struct sph_particle { float x, y, u, v, m, rho, p; } sph_particle;
+
+/* the reference's compile-time constants (:11-20) and domain box (:595) as run-time parameters */
+typedef struct sph_params {
+    float r;      /* R      initial particle spacing [m]       :11 */
+    float h;      /* H      smoothing length = 1.3 R           :12 */
+    float rho0;   /* RHO_0  reference density                  :15 */
+    float c;      /* C      numerical speed of sound           :16 */
+    float g;      /* G      gravitational acceleration         :17 */
+    float dt;     /* DT     time step = H/C                    :19 */
+    float vol;    /* V      fluid particle volume = 0.57 H^2   :20 */
+    float x_min, x_max, y_min, y_max;   /* neighbour-grid domain, :595 ({0,WIDTH,0,HEIGHT}) */
+    float alpha;  /* 0.01   artificial viscosity               :334 */
+    float eps;    /* 0.01   viscosity singularity guard        :332 */
+    float k1;     /* 0.1    artificial pressure strength       :325 */
+    float k2;     /* 0.2    artificial pressure reference q    :325 */
+} sph_params;
+
+typedef struct sph_ctx sph_ctx;
+
+/* names of the per-step kernels, in launch order (index into sph_kernel_times.ms) */
+enum {
+    SPH_K_KICK_DRIFT_KEY = 0,  /* :615-624 + cell index of :111-113 + histogram */
+    SPH_K_SCAN_REDUCE    = 1,  /* counting sort: per-block cell-count sums       */
+    SPH_K_SCAN_APPLY     = 2,  /* counting sort: exclusive scan -> cell_start    */
+    SPH_K_REORDER        = 3,  /* counting sort: scatter to cell-contiguous order (replaces the linked list of :104-124) */
+    SPH_K_DENSITY_EOS    = 4,  /* :263-289 + :294-301                            */
+    SPH_K_FORCE_KICK     = 5,  /* :303-373 + :637-640                            */
+    SPH_K_HALO           = 6,  /* slab mode only: halo pack/ingest               */
+    SPH_K_COUNT          = 7
+};
+typedef struct sph_kernel_times {
+    float ms[SPH_K_COUNT];     /* mean device time per launch of each kernel, HIP events on the context's stream */
+    float step_ms;             /* mean device time of one whole step */
+    int   nsteps;
+} sph_kernel_times;
+
+/* reference defaults (:11-20), box 4 x 2 */
+void sph_params_default(sph_params *prm);
+int  sph_abi_version(void);
+const char *sph_error_string(int err);
+/* number of usable HIP devices (0 when there is none; never initialises a context) */
+int  sph_device_count(void);
+
+/* Replaces the init sequence :594-607 (alloc_neighbors_context x2, update_neighbors_context,
+ * calculate_boundary_pseudomass, first calculate_density/_particle_pressure/_accelerations).
+ * Copies fluid[0..n_fluid) (x,y,u,v; m must equal rho0*vol) and boundary[0..n_boundary) (x,y),
+ * computes psi, bins everything, evaluates rho, p and a at t = 0 under gravity (gx,gy).
+ * device = HIP device ordinal. */
+int  sph_create(sph_ctx **out, const sph_params *prm,
+                const sph_particle *fluid, int n_fluid,
+                const sph_particle *boundary, int n_boundary,
+                float gx, float gy, int device);
+void sph_destroy(sph_ctx *ctx);
+const char *sph_last_error(const sph_ctx *ctx);
+
+/* Replaces the loop body :612-641, nsteps times: kick 1/2, drift, rebuild the neighbour
+ * structure, density, pressure, acceleration under (gx,gy), kick 1/2.  The reference re-reads
+ * g every step (:632); here it is sampled once per call.  Asynchronous. */
+int  sph_step(sph_ctx *ctx, float gx, float gy, int nsteps);
+/* wait for all enqueued work; reports SPH_E_OUT_OF_DOMAIN / SPH_E_NAN seen since the last sync */
+int  sph_sync(sph_ctx *ctx);
+
+/* Read-back in ORIGINAL particle order (what main() reads from fluid[] at :649, :657-671).
+ * out[i] = {x,y,u,v,m,rho,p} of the particle given as fluid[i] to sph_create. */
+int  sph_read_particles(sph_ctx *ctx, sph_particle *out);
+/* du_dt[], dv_dt[] of :492-493, original order */
+int  sph_read_accel(sph_ctx *ctx, float *du_dt, float *dv_dt);
+/* boundary particles, original order, psi in .m (:259) */
+int  sph_read_boundary(sph_ctx *ctx, sph_particle *out);
+/* the statistics of :657-671 as device reductions: max rho and max sqrt(u^2+v^2) over fluid */
+int  sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed);
+
+int  sph_n_fluid(const sph_ctx *ctx);
+int  sph_n_boundary(const sph_ctx *ctx);
+/* n_cells (rows, y) and m_cells (columns, x) as :93-94 computes them */
+int  sph_grid_dims(const sph_ctx *ctx, int *n_cells, int *m_cells);
+/* total particles clamped into the domain so far (0 in a healthy run) */
+long long sph_out_of_domain_count(sph_ctx *ctx);
+
+/* ---- stage entry points: the individual calculate_* calls, for staged parity gates ---- */
+/* overwrite x,y,u,v AND rho,p of every fluid particle (original order) and re-bin (:604) */
+int  sph_upload_state(sph_ctx *ctx, const sph_particle *fluid);
+int  sph_eval_density(sph_ctx *ctx);                       /* calculate_density :263-289, rho only */
+int  sph_eval_pressure(sph_ctx *ctx);                      /* calculate_particle_pressure :294-301, from the stored rho */
+int  sph_eval_accel(sph_ctx *ctx, float gx, float gy);     /* calculate_accelerations :303-373, from the stored x,y,u,v,rho,p */
+
+/* ---- measurement ---- */
+/* run nsteps steps eagerly with HIP events around every kernel (same kernels as sph_step) */
+int  sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_times *out);
+/* adopt an existing hipStream_t (e.g. the host framework's current stream); NULL = own stream */
+int  sph_set_stream(sph_ctx *ctx, void *hip_stream);
+/* device bytes held by the context */
+size_t sph_device_bytes(const sph_ctx *ctx);
+/* select kernel variant for density/force: 0 = default (best), others for A/B measurements */
+int  sph_set_variant(sph_ctx *ctx, int variant);
+
+/* ---- metaball renderer (next row f1): draw_metaballs :380-411 + pixel grid :570-577 ----
+ * 128 x 64 1-bpp SSD1306 page-format bitmap, 1024 bytes: bit (i%8) of byte (i/8)*128+j. */
+int  sph_render_metaballs(sph_ctx *ctx, unsigned char *draw_buffer_1024);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_H */

@@ -1,0 +1,70 @@
+/* sph_host.h — host-side C helpers of the stepper (libsph_host.so, plain C, no GPU).
+ *
+ * These mirror the parts of the reference's main() that sit on either side of the hot
+ * path: scene generation (pi_sph_fluid.c:484-540, :238-240) and the gravity source
+ * (:431-464).  They produce / consume the same `struct particle` arrays main() does,
+ * so the C host (pi-sph-fluid_amd/host/desktop_sph_fluid.c), the tests and bench.py
+ * all build their inputs through one implementation.
+ */
+#ifndef SPH_HOST_H
+#define SPH_HOST_H
+
+#include "sph.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* All generators follow one protocol: with out == NULL they return the number of particles
+ * the scene has; otherwise they fill out[0..cap) and return the number written (or
+ * SPH_E_ARG when cap is too small).  u = v = 0, rho = rho0, p = 0; fluid m = rho0*vol,
+ * boundary m = 0 (psi is computed by sph_create). */
+
+/* The exact default scene of the reference: lattice positions by f32 accumulation from 0
+ * (x outer, y inner, :486-488/:497-498), kept where euclid_dist(x,y,WIDTH/2,HEIGHT/2) < 0.70
+ * (:238-240).  With the default parameters: 269 particles. */
+long sph_scene_default_fluid(const sph_params *prm, sph_particle *out, long cap);
+
+/* The wall generator of :523-540 for the box of prm: for every lattice x: (x,y_min),(x,y_max);
+ * for every lattice y: (x_min,y),(x_max,y).  accumulate != 0 reproduces the reference's f32
+ * accumulation (default scene: 162 particles, corner (0,0) duplicated, corner (W,H) absent);
+ * accumulate == 0 uses x = x_min + i*R (large boxes). */
+long sph_scene_walls(const sph_params *prm, int accumulate, sph_particle *out, long cap);
+
+/* Disc of lattice points (x = i*R, y = j*R, i outer / j inner) with distance < radius from
+ * (cx,cy): the "drop on dry surface" scene scaled up (cfg1). */
+long sph_scene_disc(const sph_params *prm, float cx, float cy, float radius, sph_particle *out, long cap);
+
+/* nx x ny lattice block with its lower-left particle at (x0,y0), x = x0 + i*R (i outer, j inner):
+ * the dam-break scenes (cfg2-4). */
+long sph_scene_block(const sph_params *prm, float x0, float y0, long nx, long ny, sph_particle *out, long cap);
+
+/* ---- gravity source: get_gravity / get_gravity_routine (:431-464) ---- */
+typedef enum sph_gravity_kind {
+    SPH_GRAVITY_CONSTANT = 0,   /* (0,-G): the non-MPU6050 branch :442-443 */
+    SPH_GRAVITY_TILT = 1,       /* scripted trace g = G(sin th, -cos th), th = amp*sin(2 pi t/period) (cfg4) */
+    SPH_GRAVITY_MPU6050 = 2     /* sysfs IIO reader, :436-440 */
+} sph_gravity_kind;
+
+typedef struct sph_gravity {
+    int kind;
+    float g;               /* magnitude G */
+    float amp_deg;         /* tilt amplitude, degrees */
+    float period_s;        /* tilt period, seconds of simulated time */
+    float hold_s;          /* zero-order hold (the 10 Hz poll of :455-461): 0.1 */
+    char  sysfs_dir[256];  /* MPU6050: directory holding in_accel_{x,y}_raw */
+    /* state */
+    float last_t, gx, gy;
+    int   primed;
+} sph_gravity;
+
+void sph_gravity_init(sph_gravity *gs, int kind, float g);
+/* gravity vector at simulated time t, re-sampled at most every hold_s of simulated time
+ * (the reference polls every 100 ms of wall time, which equals simulated time under REALTIME).
+ * Returns 0, or SPH_E_ARG when the MPU6050 files cannot be read (reference: exit(1), :419-422). */
+int  sph_gravity_sample(sph_gravity *gs, float t, float *gx, float *gy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_HOST_H */

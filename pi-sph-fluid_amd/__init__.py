@@ -1,0 +1,333 @@
+"""pi-sph-fluid_amd — MI355X-native 2-D WCSPH stepper (host-side Python binding).
+
+The product is the C-ABI library ``csrc/libsph_hip.so`` (hand-written gfx950 kernels,
+include/sph.h) plus the plain-C host helpers ``host/libsph_host.so`` (include/sph_host.h).
+This module is a thin ctypes mirror of those two headers, used by tests/ and bench.py; the
+C host program lives in host/desktop_sph_fluid.c.  The directory name has a hyphen, so import
+it with ``importlib.import_module("pi-sph-fluid_amd")``.
+
+There is no CPU compute path here: creating a :class:`Context` without a gfx950 GPU raises
+:class:`SphError` (SPH_E_HIP).  The CPU oracle under ``oracle/`` is test infrastructure and is
+never imported from this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_HIP = os.path.join(HERE, "csrc", "libsph_hip.so")
+LIB_HOST = os.path.join(HERE, "host", "libsph_host.so")
+
+# byte-compatible with the reference's `struct particle` (pi_sph_fluid.c:26-31)
+PARTICLE = np.dtype([("x", "<f4"), ("y", "<f4"), ("u", "<f4"), ("v", "<f4"),
+                     ("m", "<f4"), ("rho", "<f4"), ("p", "<f4")])
+
+SPH_OK, SPH_E_ARG, SPH_E_HIP, SPH_E_OUT_OF_DOMAIN, SPH_E_NAN = 0, -1, -2, -3, -4
+SPH_E_NOMEM, SPH_E_CAPACITY, SPH_E_STATE = -5, -6, -7
+KERNEL_NAMES = ["kick_drift_key", "scan_reduce", "scan_apply", "reorder", "density_eos", "force_kick", "halo"]
+# algorithmic HBM bytes per fluid particle per launch (scan is per cell)
+KERNEL_ALGO_BYTES = {"kick_drift_key": 44.0 + 5.2, "reorder": 44.0, "density_eos": 16.6, "force_kick": 40.0}
+STEP_ALGO_BYTES = 152.0
+
+# every symbol include/sph.h and include/sph_host.h declare
+ABI_SYMBOLS = [
+    "sph_params_default", "sph_abi_version", "sph_error_string", "sph_device_count",
+    "sph_create", "sph_destroy", "sph_last_error", "sph_step", "sph_sync",
+    "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_stats",
+    "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_out_of_domain_count",
+    "sph_upload_state", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
+    "sph_profile_steps", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
+    "sph_render_metaballs",
+]
+HOST_SYMBOLS = [
+    "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",
+    "sph_gravity_init", "sph_gravity_sample",
+]
+
+
+class Params(C.Structure):
+    """sph_params of include/sph.h (the reference's #defines :11-20 + the box of :595)."""
+    _fields_ = [("r", C.c_float), ("h", C.c_float), ("rho0", C.c_float), ("c", C.c_float),
+                ("g", C.c_float), ("dt", C.c_float), ("vol", C.c_float),
+                ("x_min", C.c_float), ("x_max", C.c_float), ("y_min", C.c_float), ("y_max", C.c_float),
+                ("alpha", C.c_float), ("eps", C.c_float), ("k1", C.c_float), ("k2", C.c_float)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_float * 7), ("step_ms", C.c_float), ("nsteps", C.c_int)]
+
+
+class Gravity(C.Structure):
+    _fields_ = [("kind", C.c_int), ("g", C.c_float), ("amp_deg", C.c_float), ("period_s", C.c_float),
+                ("hold_s", C.c_float), ("sysfs_dir", C.c_char * 256),
+                ("last_t", C.c_float), ("gx", C.c_float), ("gy", C.c_float), ("primed", C.c_int)]
+
+
+GRAVITY_CONSTANT, GRAVITY_TILT, GRAVITY_MPU6050 = 0, 1, 2
+
+
+class SphError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("sph error %d: %s" % (code, message))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile every native piece for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", HERE, "all"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    """The C-ABI library; raises loudly when it is not built (no fallback)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(LIB_HIP):
+            raise SphError(SPH_E_HIP, "%s not built — run `make -C %s` (there is no CPU fallback)" % (LIB_HIP, HERE))
+        L = C.CDLL(LIB_HIP)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.sph_params_default.argtypes = [C.POINTER(Params)]
+        L.sph_error_string.restype = C.c_char_p
+        L.sph_error_string.argtypes = [ci]
+        L.sph_create.argtypes = [C.POINTER(vp), C.POINTER(Params), vp, ci, vp, ci, cf, cf, ci]
+        L.sph_destroy.argtypes = [vp]
+        L.sph_destroy.restype = None
+        L.sph_last_error.argtypes = [vp]
+        L.sph_last_error.restype = C.c_char_p
+        L.sph_step.argtypes = [vp, cf, cf, ci]
+        L.sph_sync.argtypes = [vp]
+        L.sph_read_particles.argtypes = [vp, vp]
+        L.sph_read_accel.argtypes = [vp, vp, vp]
+        L.sph_read_boundary.argtypes = [vp, vp]
+        L.sph_stats.argtypes = [vp, C.POINTER(cf), C.POINTER(cf)]
+        L.sph_n_fluid.argtypes = [vp]
+        L.sph_n_boundary.argtypes = [vp]
+        L.sph_grid_dims.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+        L.sph_out_of_domain_count.argtypes = [vp]
+        L.sph_out_of_domain_count.restype = C.c_longlong
+        L.sph_upload_state.argtypes = [vp, vp]
+        L.sph_eval_density.argtypes = [vp]
+        L.sph_eval_pressure.argtypes = [vp]
+        L.sph_eval_accel.argtypes = [vp, cf, cf]
+        L.sph_profile_steps.argtypes = [vp, cf, cf, ci, C.POINTER(KernelTimes)]
+        L.sph_set_stream.argtypes = [vp, vp]
+        L.sph_device_bytes.argtypes = [vp]
+        L.sph_device_bytes.restype = C.c_size_t
+        L.sph_set_variant.argtypes = [vp, ci]
+        L.sph_render_metaballs.argtypes = [vp, vp]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(LIB_HOST):
+            raise SphError(SPH_E_ARG, "%s not built — run `make -C %s`" % (LIB_HOST, HERE))
+        L = C.CDLL(LIB_HOST)
+        vp, cl, cf = C.c_void_p, C.c_long, C.c_float
+        L.sph_params_default.argtypes = [C.POINTER(Params)]
+        L.sph_scene_default_fluid.argtypes = [C.POINTER(Params), vp, cl]
+        L.sph_scene_default_fluid.restype = cl
+        L.sph_scene_walls.argtypes = [C.POINTER(Params), C.c_int, vp, cl]
+        L.sph_scene_walls.restype = cl
+        L.sph_scene_disc.argtypes = [C.POINTER(Params), cf, cf, cf, vp, cl]
+        L.sph_scene_disc.restype = cl
+        L.sph_scene_block.argtypes = [C.POINTER(Params), cf, cf, cl, cl, vp, cl]
+        L.sph_scene_block.restype = cl
+        L.sph_gravity_init.argtypes = [C.POINTER(Gravity), C.c_int, cf]
+        L.sph_gravity_init.restype = None
+        L.sph_gravity_sample.argtypes = [C.POINTER(Gravity), cf, C.POINTER(cf), C.POINTER(cf)]
+        _host = L
+    return _host
+
+
+def default_params(box=None):
+    p = Params()
+    host_lib().sph_params_default(C.byref(p))
+    if box is not None:
+        p.x_min, p.x_max, p.y_min, p.y_max = [float(v) for v in box]
+    return p
+
+
+def _two_call(fn, *args):
+    n = fn(*args, None, 0)
+    if n < 0:
+        raise SphError(int(n), "scene generator rejected its arguments")
+    out = np.zeros(n, PARTICLE)
+    m = fn(*args, out.ctypes.data_as(C.c_void_p), n)
+    if m != n:
+        raise SphError(int(m), "scene generator size mismatch")
+    return out
+
+
+# ---- scenes ----
+def scene_default(prm=None):
+    """cfg0: the exact default scene of the reference (269 fluid + 162 boundary)."""
+    prm = prm or default_params()
+    L = host_lib()
+    return prm, _two_call(L.sph_scene_default_fluid, C.byref(prm)), _two_call(L.sph_scene_walls, C.byref(prm), 1)
+
+
+def scene_disc(box, cx, cy, radius):
+    prm = default_params(box)
+    L = host_lib()
+    return prm, _two_call(L.sph_scene_disc, C.byref(prm), cx, cy, radius), _two_call(L.sph_scene_walls, C.byref(prm), 0)
+
+
+def scene_block(box, x0, y0, nx, ny):
+    prm = default_params(box)
+    L = host_lib()
+    return prm, _two_call(L.sph_scene_block, C.byref(prm), x0, y0, nx, ny), _two_call(L.sph_scene_walls, C.byref(prm), 0)
+
+
+def scene(name):
+    """Named configurations of BASELINE.json / SURVEY.md §8d."""
+    if name == "cfg0":
+        return scene_default()
+    if name == "cfg1":      # 256k-particle drop on a dry surface
+        return scene_disc((0.0, 409.6, 0.0, 204.8), 204.8, 30.95, 21.665)
+    if name == "cfg2":      # 2M dam break
+        return scene_block((0.0, 1200.0, 0.0, 60.0), 0.3, 0.3, 4000, 500)
+    if name == "cfg3":      # 8M dam break (4 x-slabs)
+        return scene_block((0.0, 2400.0, 0.0, 60.0), 0.3, 0.3, 16000, 500)
+    if name == "cfg4":      # 32M tank (8 x-slabs)
+        return scene_block((0.0, 2400.6, 0.0, 150.0), 0.3, 0.3, 32000, 1000)
+    raise ValueError("unknown scene %r" % name)
+
+
+def dam_break(n_slabs):
+    """The cfg2 -> cfg3 family: one 4000 x 500 block (2M particles, 1200 m of box) per slab."""
+    return scene_block((0.0, 1200.0 * n_slabs, 0.0, 60.0), 0.3, 0.3, 4000 * n_slabs, 500)
+
+
+class GravitySource:
+    """get_gravity / get_gravity_routine of the reference (:431-464) behind one sample(t) call."""
+
+    def __init__(self, kind=GRAVITY_CONSTANT, g=9.81, **kw):
+        self.s = Gravity()
+        host_lib().sph_gravity_init(C.byref(self.s), kind, g)
+        for k, v in kw.items():
+            setattr(self.s, k, v.encode() if k == "sysfs_dir" else v)
+
+    def sample(self, t):
+        gx, gy = C.c_float(), C.c_float()
+        rc = host_lib().sph_gravity_sample(C.byref(self.s), t, C.byref(gx), C.byref(gy))
+        if rc:
+            raise SphError(rc, "gravity source failed")
+        return gx.value, gy.value
+
+
+class Context:
+    """One sph_ctx: the init/step/read-back surface of include/sph.h."""
+
+    def __init__(self, prm, fluid, boundary, gx=0.0, gy=-9.81, device=0):
+        self.L = hip_lib()
+        self.h = C.c_void_p()
+        fluid = np.ascontiguousarray(fluid, PARTICLE)
+        boundary = np.ascontiguousarray(boundary, PARTICLE)
+        self.n, self.nb = len(fluid), len(boundary)
+        rc = self.L.sph_create(C.byref(self.h), C.byref(prm), fluid.ctypes.data_as(C.c_void_p), self.n,
+                               boundary.ctypes.data_as(C.c_void_p), self.nb, gx, gy, device)
+        if rc:
+            msg = self.L.sph_last_error(self.h).decode() if self.h else "sph_create failed"
+            self.close()
+            raise SphError(rc, msg)
+
+    def _chk(self, rc):
+        if rc:
+            raise SphError(rc, self.L.sph_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def step(self, nsteps=1, gx=0.0, gy=-9.81):
+        self._chk(self.L.sph_step(self.h, gx, gy, nsteps))
+
+    def sync(self):
+        self._chk(self.L.sph_sync(self.h))
+
+    def read_particles(self):
+        out = np.zeros(self.n, PARTICLE)
+        self._chk(self.L.sph_read_particles(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def read_accel(self):
+        du, dv = np.zeros(self.n, np.float32), np.zeros(self.n, np.float32)
+        self._chk(self.L.sph_read_accel(self.h, du.ctypes.data_as(C.c_void_p), dv.ctypes.data_as(C.c_void_p)))
+        return du, dv
+
+    def read_boundary(self):
+        out = np.zeros(self.nb, PARTICLE)
+        self._chk(self.L.sph_read_boundary(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def stats(self):
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.L.sph_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def grid_dims(self):
+        a, b = C.c_int(), C.c_int()
+        self._chk(self.L.sph_grid_dims(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def out_of_domain(self):
+        return int(self.L.sph_out_of_domain_count(self.h))
+
+    def upload_state(self, fluid):
+        fluid = np.ascontiguousarray(fluid, PARTICLE)
+        assert len(fluid) == self.n
+        self._chk(self.L.sph_upload_state(self.h, fluid.ctypes.data_as(C.c_void_p)))
+
+    def eval_density(self):
+        self._chk(self.L.sph_eval_density(self.h))
+
+    def eval_pressure(self):
+        self._chk(self.L.sph_eval_pressure(self.h))
+
+    def eval_accel(self, gx=0.0, gy=-9.81):
+        self._chk(self.L.sph_eval_accel(self.h, gx, gy))
+
+    def profile_steps(self, nsteps, gx=0.0, gy=-9.81):
+        kt = KernelTimes()
+        self._chk(self.L.sph_profile_steps(self.h, gx, gy, nsteps, C.byref(kt)))
+        d = {KERNEL_NAMES[k]: kt.ms[k] for k in range(6)}
+        d["step"] = kt.step_ms
+        return d
+
+    def set_stream(self, hip_stream):
+        self._chk(self.L.sph_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def set_variant(self, variant):
+        self._chk(self.L.sph_set_variant(self.h, variant))
+
+    def device_bytes(self):
+        return int(self.L.sph_device_bytes(self.h))
+
+    def render_metaballs(self):
+        buf = np.zeros(1024, np.uint8)
+        self._chk(self.L.sph_render_metaballs(self.h, buf.ctypes.data_as(C.c_void_p)))
+        return buf

@@ -1,0 +1,477 @@
+// sph_abi.hip — the C ABI of include/sph.h on top of the gfx950 kernels.
+//
+// Host-side orchestration only: device memory, the HIP stream, the captured step graph,
+// read-backs.  All arithmetic on particles happens in sph_kernels.hip.  There is no CPU
+// compute path: every entry point that needs a GPU fails with SPH_E_HIP when none is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sph.h"
+#include "sph_internal.h"
+
+using namespace sph;
+
+struct sph_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    sph_params prm{};
+    Consts c{};
+    Arrays a{};
+    int n = 0, nb = 0;
+    int variant = 0;
+    sph_particle *d_aos = nullptr;    // n  : read-back / upload staging, original order
+    sph_particle *d_baos = nullptr;   // nb
+    float *d_du = nullptr, *d_dv = nullptr;
+    unsigned char *d_bits = nullptr;  // 8192 metaball pixels
+    std::vector<void *> allocs;
+    size_t bytes = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool use_graph = true;
+    hipEvent_t ev[SPH_K_COUNT + 2] = {};
+    long long oob_total = 0, nan_total = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(sph_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), sph_error_string(code));
+        else snprintf(buf, sizeof buf, "%s (%s)", what, sph_error_string(code));
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                         \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) return fail((ctx), SPH_E_HIP, #call, e_);           \
+    } while (0)
+
+template <typename T>
+int dalloc(sph_ctx *ctx, T **p, size_t count) {
+    size_t b = (count ? count : 1) * sizeof(T);
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, b);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? SPH_E_NOMEM : SPH_E_HIP, "hipMalloc", e);
+    ctx->allocs.push_back(q);
+    ctx->bytes += b;
+    *p = static_cast<T *>(q);
+    return SPH_OK;
+}
+
+// derived constants, evaluated like the reference's macros (double where its expression is double)
+int make_consts(const sph_params &p, Consts &c) {
+    if (!(p.h > 0) || !(p.r > 0) || !(p.rho0 > 0) || !(p.c > 0) || !(p.dt > 0) || !(p.vol > 0)) return SPH_E_ARG;
+    if (!(p.x_max > p.x_min) || !(p.y_max > p.y_min)) return SPH_E_ARG;
+    const double H = p.h;
+    const double nf = 7.0 / (4.0 * M_PI * H * H);                       // :46
+    c.h = p.h;
+    c.inv_h = 1.0f / p.h;
+    const float two_h = 2 * p.h;                                         // :144
+    c.cut2 = two_h * two_h;
+    c.nf = (float)nf;
+    c.grad_c = (float)(5.0 * nf / (H * H));                              // :56-59
+    const double q = p.k2;                                               // W(0.2 H): q = 0.2   :325
+    const double t = 1.0 - 0.5 * q;
+    c.inv_w_k2h = (float)(1.0 / (nf * t * t * t * t * (1.0 + 2.0 * q)));
+    c.k1 = p.k1;
+    c.eps_h2 = (float)((double)p.eps * H * H);                           // :332
+    c.visc_c = (float)((double)p.alpha * (double)p.c * H);               // :332, :334
+    c.m_fluid = p.rho0 * p.vol;                                          // :502
+    c.rho0 = p.rho0;
+    c.inv_rho0 = 1.0f / p.rho0;
+    c.B = p.c * p.c * p.rho0 / 7;                                        // :297
+    c.dt = p.dt;
+    c.half_dt = (float)(0.5 * (double)p.dt);                             // :616
+    c.x_min = p.x_min;
+    c.y_min = p.y_min;
+    c.cell = 2 * p.h;                                                    // :596
+    double rows = (double)(int)((p.y_max - p.y_min) / c.cell) + 1;       // :93
+    double cols = (double)(int)((p.x_max - p.x_min) / c.cell) + 1;       // :94
+    if (rows * cols > 1.0e9) return SPH_E_ARG;
+    c.rows = (int)rows;
+    c.cols = (int)cols;
+    c.n_cells = c.rows * c.cols;
+    return SPH_OK;
+}
+
+size_t padded_items(const Consts &c) {
+    size_t n_items = (size_t)c.n_cells + 1;
+    return (n_items + SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
+}
+
+// the six launches of one time step (SPH_K_* order); ev != nullptr records an event before each
+void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
+    hipStream_t st = ctx->stream;
+    if (ev) (void)hipEventRecord(ev[SPH_K_KICK_DRIFT_KEY], st);
+    launch_kick_drift_key(st, ctx->c, ctx->a, ctx->n);
+    if (ev) (void)hipEventRecord(ev[SPH_K_SCAN_REDUCE], st);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.cell_start, ctx->a.block_sums, ev ? ev[SPH_K_SCAN_APPLY] : nullptr);
+    if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
+    launch_reorder(st, ctx->c, ctx->a, ctx->n);
+    if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
+    launch_density(st, ctx->c, ctx->a, ctx->n, true, ctx->variant);
+    if (ev) (void)hipEventRecord(ev[SPH_K_FORCE_KICK], st);
+    launch_force(st, ctx->c, ctx->a, ctx->n, true, ctx->variant);
+    if (ev) (void)hipEventRecord(ev[SPH_K_HALO], st);   // = end of step
+}
+
+void drop_graph(sph_ctx *ctx) {
+    if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
+    if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+}
+
+// capture one step into a graph (launch-latency bound at small N; replay costs one submission)
+bool ensure_graph(sph_ctx *ctx) {
+    if (!ctx->use_graph) return false;
+    if (ctx->gexec) return true;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->use_graph = false;
+        return false;
+    }
+    enqueue_step(ctx, nullptr);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &ctx->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&ctx->gexec, ctx->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        drop_graph(ctx);
+        ctx->use_graph = false;
+        return false;
+    }
+    return true;
+}
+
+// bin the current (pos, velt, id) state: keys + histogram, scan, scatter; then velt := sorted vel
+int resort_state(sph_ctx *ctx) {
+    hipStream_t st = ctx->stream;
+    launch_key_only(st, ctx->c, ctx->a, ctx->n);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.cell_start, ctx->a.block_sums, nullptr);
+    launch_reorder(st, ctx->c, ctx->a, ctx->n);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->a.velt, ctx->a.vel, sizeof(float2) * (size_t)ctx->n, hipMemcpyDeviceToDevice, st));
+    return SPH_OK;
+}
+
+int check_flags(sph_ctx *ctx) {
+    uint32_t h[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[0] | h[1]) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->a.flags, 0, sizeof h, ctx->stream));
+        ctx->oob_total += h[FLAG_OOB];
+        ctx->nan_total += h[FLAG_NAN];
+        if (h[FLAG_NAN]) return fail(ctx, SPH_E_NAN, "particle positions became NaN/Inf");
+        return fail(ctx, SPH_E_OUT_OF_DOMAIN, "particles left the domain and were clamped into edge cells");
+    }
+    return SPH_OK;
+}
+
+int select_device(sph_ctx *ctx, int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(ctx, SPH_E_HIP, "no HIP device available (this library has no CPU path)", e);
+    }
+    if (device < 0 || device >= count) return fail(ctx, SPH_E_ARG, "device ordinal out of range");
+    HIPCHK(ctx, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(ctx, SPH_E_HIP, "device is not gfx950 (MI355X); kernels are built for gfx950 only");
+    ctx->device = device;
+    return SPH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sph_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+const char *sph_last_error(const sph_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void sph_destroy(sph_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    drop_graph(ctx);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int sph_create(sph_ctx **out, const sph_params *prm, const sph_particle *fluid, int n_fluid,
+               const sph_particle *boundary, int n_boundary, float gx, float gy, int device) {
+    if (!out) return SPH_E_ARG;
+    *out = nullptr;
+    sph_ctx *ctx = new sph_ctx();
+    *out = ctx;   // returned even on failure so that sph_last_error() can be read; caller destroys it
+    if (!prm || n_fluid < 0 || n_boundary < 0 || (n_fluid > 0 && !fluid) || (n_boundary > 0 && !boundary))
+        return fail(ctx, SPH_E_ARG, "sph_create: null pointer or negative count");
+    ctx->prm = *prm;
+    if (make_consts(*prm, ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "sph_create: invalid parameters or grid too large");
+    for (int i = 0; i < n_fluid; i++)
+        if (std::fabs(fluid[i].m - ctx->c.m_fluid) > 1e-6f * ctx->c.m_fluid)
+            return fail(ctx, SPH_E_ARG, "sph_create: fluid mass must be uniform and equal rho0*vol (pi_sph_fluid.c:502)");
+    int rc = select_device(ctx, device);
+    if (rc) return rc;
+    ctx->n = n_fluid;
+    ctx->nb = n_boundary;
+    if (const char *e = getenv("SPH_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
+    if (const char *e = getenv("SPH_VARIANT")) ctx->variant = atoi(e);
+
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+    for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
+
+    Arrays &a = ctx->a;
+    const size_t n = (size_t)n_fluid, nb = (size_t)n_boundary, pad = padded_items(ctx->c);
+    const size_t tiles = pad / SCAN_TILE;
+#define ALLOC(ptr, cnt) if ((rc = dalloc(ctx, &(ptr), (cnt))) != SPH_OK) return rc
+    ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
+    ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.slot, n > nb ? n : nb);
+    ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
+    ALLOC(a.bpos, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
+    ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT);
+    ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 64 * 128);
+    float2 *bpos_in = nullptr;
+    uint32_t *bkey = nullptr;
+    ALLOC(bpos_in, nb); ALLOC(bkey, nb);
+#undef ALLOC
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(a.acc, 0, (n ? n : 1) * sizeof(float2), st));
+
+    // boundary: bin once, pseudo-mass once (:600-601)
+    std::vector<float2> hb(nb ? nb : 1);
+    for (size_t i = 0; i < nb; i++) hb[i] = make_float2(boundary[i].x, boundary[i].y);
+    HIPCHK(ctx, hipMemcpyAsync(bpos_in, hb.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
+    launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.flags, n_boundary);
+    launch_scan(st, ctx->c, a.count, a.bcell_start, a.block_sums, nullptr);
+    launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary);
+    launch_boundary_psi(st, ctx->c, a, n_boundary);
+
+    // fluid: upload, bin, then rho, p, a at t = 0 (:604-607)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, n * sizeof(sph_particle), hipMemcpyHostToDevice, st));
+    launch_upload_state(st, a, n_fluid, ctx->d_aos);
+    if ((rc = resort_state(ctx)) != SPH_OK) return rc;
+    launch_set_gravity(st, a, gx, gy);
+    launch_density(st, ctx->c, a, n_fluid, true, ctx->variant);
+    launch_force(st, ctx->c, a, n_fluid, false, ctx->variant);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));   // also keeps hb / fluid alive until the copies are done
+    rc = check_flags(ctx);
+    return rc;
+}
+
+int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
+    if (!ctx || nsteps < 0) return SPH_E_ARG;
+    if (!ctx->stream) return fail(ctx, SPH_E_STATE, "context not initialised");
+    (void)hipSetDevice(ctx->device);
+    launch_set_gravity(ctx->stream, ctx->a, gx, gy);
+    const bool g = ensure_graph(ctx);
+    for (int s = 0; s < nsteps; s++) {
+        if (g) HIPCHK(ctx, hipGraphLaunch(ctx->gexec, ctx->stream));
+        else enqueue_step(ctx, nullptr);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_sync(sph_ctx *ctx) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    return check_flags(ctx);
+}
+
+int sph_read_particles(sph_ctx *ctx, sph_particle *out) {
+    if (!ctx || !ctx->stream || (!out && ctx->n)) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_unsort_particles(ctx->stream, ctx->c, ctx->a, ctx->n, ctx->d_aos);
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_aos, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPH_OK;
+}
+
+int sph_read_accel(sph_ctx *ctx, float *du_dt, float *dv_dt) {
+    if (!ctx || !ctx->stream || ((!du_dt || !dv_dt) && ctx->n)) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_unsort_accel(ctx->stream, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
+    HIPCHK(ctx, hipMemcpyAsync(du_dt, ctx->d_du, (size_t)ctx->n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dv_dt, ctx->d_dv, (size_t)ctx->n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPH_OK;
+}
+
+int sph_read_boundary(sph_ctx *ctx, sph_particle *out) {
+    if (!ctx || !ctx->stream || (!out && ctx->nb)) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_unsort_boundary(ctx->stream, ctx->c, ctx->a, ctx->nb, ctx->d_baos);
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_baos, (size_t)ctx->nb * sizeof(sph_particle), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPH_OK;
+}
+
+int sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_MAXRHO, 0, 2 * sizeof(uint32_t), ctx->stream));
+    launch_stats(ctx->stream, ctx->a, ctx->n);
+    uint32_t h[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags + FLAG_MAXRHO, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float r, s;
+    memcpy(&r, &h[0], 4);
+    memcpy(&s, &h[1], 4);
+    if (max_rho) *max_rho = r;
+    if (max_speed) *max_speed = s;
+    return SPH_OK;
+}
+
+int sph_n_fluid(const sph_ctx *ctx) { return ctx ? ctx->n : SPH_E_ARG; }
+int sph_n_boundary(const sph_ctx *ctx) { return ctx ? ctx->nb : SPH_E_ARG; }
+int sph_grid_dims(const sph_ctx *ctx, int *n_cells, int *m_cells) {
+    if (!ctx) return SPH_E_ARG;
+    if (n_cells) *n_cells = ctx->c.rows;
+    if (m_cells) *m_cells = ctx->c.cols;
+    return SPH_OK;
+}
+long long sph_out_of_domain_count(sph_ctx *ctx) {
+    if (!ctx) return SPH_E_ARG;
+    if (ctx->stream) (void)check_flags(ctx);
+    return ctx->oob_total;
+}
+size_t sph_device_bytes(const sph_ctx *ctx) { return ctx ? ctx->bytes : 0; }
+
+int sph_set_variant(sph_ctx *ctx, int variant) {
+    if (!ctx || variant < 0 || variant > 1) return SPH_E_ARG;
+    if (variant != ctx->variant) {
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        drop_graph(ctx);
+        ctx->variant = variant;
+    }
+    return SPH_OK;
+}
+
+int sph_set_stream(sph_ctx *ctx, void *hip_stream) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graph(ctx);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (hip_stream) {
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    } else {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return SPH_OK;
+}
+
+// ---- stage entry points ----
+int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
+    if (!ctx || !ctx->stream || (!fluid && ctx->n)) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyHostToDevice, st));
+    launch_upload_state(st, ctx->a, ctx->n, ctx->d_aos);
+    int rc = resort_state(ctx);
+    if (rc) return rc;
+    launch_gather_rho_p(st, ctx->c, ctx->a, ctx->n, ctx->d_aos);
+    HIPCHK(ctx, hipGetLastError());
+    return check_flags(ctx);
+}
+
+int sph_eval_density(sph_ctx *ctx) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_density(ctx->stream, ctx->c, ctx->a, ctx->n, false, ctx->variant);
+    launch_eos(ctx->stream, ctx->c, ctx->a, ctx->n, true);   // keep p/rho^2 consistent with the new rho and the stored p
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_eval_pressure(sph_ctx *ctx) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_eos(ctx->stream, ctx->c, ctx->a, ctx->n, false);
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_eval_accel(sph_ctx *ctx, float gx, float gy) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_set_gravity(ctx->stream, ctx->a, gx, gy);
+    launch_force(ctx->stream, ctx->c, ctx->a, ctx->n, false, ctx->variant);
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+// ---- measurement ----
+int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_times *out) {
+    if (!ctx || !ctx->stream || !out || nsteps <= 0) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    memset(out, 0, sizeof *out);
+    launch_set_gravity(ctx->stream, ctx->a, gx, gy);
+    double acc[SPH_K_COUNT] = {0}, total = 0;
+    for (int s = 0; s < nsteps; s++) {
+        enqueue_step(ctx, ctx->ev);
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev[SPH_K_HALO]));
+        for (int k = 0; k < SPH_K_HALO; k++) {
+            float ms = 0;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
+            acc[k] += ms;
+        }
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[SPH_K_HALO]));
+        total += ms;
+    }
+    for (int k = 0; k < SPH_K_HALO; k++) out->ms[k] = (float)(acc[k] / nsteps);
+    out->step_ms = (float)(total / nsteps);
+    out->nsteps = nsteps;
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+// ---- metaballs (next row f1) ----
+int sph_render_metaballs(sph_ctx *ctx, unsigned char *draw_buffer) {
+    if (!ctx || !ctx->stream || !draw_buffer) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    unsigned char bits[64 * 128];
+    launch_metaballs(ctx->stream, ctx->c, ctx->a, ctx->prm.x_max - ctx->prm.x_min, ctx->prm.y_max - ctx->prm.y_min,
+                     ctx->d_bits);
+    HIPCHK(ctx, hipMemcpyAsync(bits, ctx->d_bits, sizeof bits, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 64; i++)          // SSD1306 page format :407-408
+        for (int j = 0; j < 128; j++) {
+            if (bits[i * 128 + j]) draw_buffer[i / 8 * 128 + j] |= (unsigned char)(1 << (i % 8));
+            else draw_buffer[i / 8 * 128 + j] &= (unsigned char)~(1 << (i % 8));
+        }
+    return SPH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// sph_internal.h — shared between the C-ABI layer (sph_abi.hip) and the kernels (sph_kernels.hip).
+// gfx950 only; not part of the public interface (that is include/sph.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sph.h"
+
+namespace sph {
+
+// Derived constants, evaluated on the host the way the reference's macros are (double where the
+// reference's expression is double, then rounded to f32), passed to kernels by value.
+struct Consts {
+    // kernel maths (pi_sph_fluid.c:45-62)
+    float h, inv_h;          // H, 1/H
+    float cut2;              // (2H)^2 : support test of :144 on squared distance
+    float nf;                // 7/(4 pi H^2)          :46
+    float grad_c;            // 5 nf / H^2 : -dW/dq / (d H) = grad_c * (1-q/2)^3   (:56-59 with q/d = 1/H)
+    float inv_w_k2h;         // 1 / W(0.2 H)          :325
+    float k1;                // 0.1                   :325
+    float eps_h2;            // 0.01 H^2              :332
+    float visc_c;            // 0.01 C H  (alpha c h) :332,:334
+    // particle / EOS (:294-301, :502)
+    float m_fluid;           // RHO_0 V
+    float rho0, inv_rho0;
+    float B;                 // C^2 RHO_0 / 7         :297
+    // integrator (:615-624, :637-640)
+    float dt, half_dt;
+    // neighbour grid (:82-124); cells are linearised COLUMN-major on the device:
+    // cell = col * rows + row, so that a column of cells (fixed x range) is one contiguous
+    // range of the sorted arrays (3 contiguous candidate ranges per particle; slab halos are
+    // contiguous).  The reference is row-major (:113); the pair sets are identical.
+    float x_min, y_min, cell; // cell length 2H :596
+    int rows, cols;          // n_cells (y), m_cells (x) :93-94
+    int n_cells;             // rows * cols
+};
+
+// Per-context device arrays. "S" = cell-sorted state, "T" = staging written by kick/drift.
+struct Arrays {
+    // fluid, sorted (S)
+    float2 *pos;       // x,y
+    float2 *vel;       // u,v (sorted copy read by the force pass)
+    uint32_t *id;      // original index
+    float2 *rp;        // rho, p/rho^2
+    float *prs;        // p
+    float2 *acc;       // du_dt, dv_dt
+    // staging (T)
+    float4 *pk;        // x, y, id bits, cell key bits (after kick/drift, before the sort)
+    float2 *velt;      // u,v : the integrated velocity lives here between steps
+    uint32_t *slot;    // arrival rank of the particle inside its cell
+    // grid
+    uint32_t *count;      // per-cell histogram (zero between sorts)
+    uint32_t *cell_start; // n_cells + 1, exclusive scan of count
+    uint32_t *block_sums; // scan scratch
+    // boundary, sorted once at init
+    float2 *bpos;
+    float *bpsi;
+    uint32_t *bid;
+    uint32_t *bcell_start; // n_cells + 1
+    // misc
+    float2 *grav;       // gravity vector read by the force kernel
+    uint32_t *flags;    // [0] out-of-domain count, [1] NaN count, [2] max rho bits, [3] max speed bits
+};
+
+enum { FLAG_OOB = 0, FLAG_NAN = 1, FLAG_MAXRHO = 2, FLAG_MAXSPEED = 3, FLAG_COUNT = 8 };
+
+constexpr int SCAN_ITEMS = 8;            // items per thread in the scan kernels
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;   // 2048 cells per block
+
+// ---- launchers (sph_kernels.hip); all asynchronous on `st` ----
+void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy);
+// first half kick + drift + cell key + histogram (:615-624, :111-113)
+void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int n);
+// keys + histogram only, state taken as is (init and sph_upload_state)
+void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int n);
+void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *cell_start, uint32_t *block_sums,
+                 hipEvent_t mid /* optional: recorded between the two scan kernels */);
+void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int n);
+// variant: 0 = LDS-tiled (default), 1 = direct global loads
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int n, bool with_eos, int variant);
+void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int n, bool from_prs);
+void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int n, bool kick, int variant);
+// boundary init: bin + pseudo-mass (:600-601, :242-261)
+void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in, uint32_t *key, uint32_t *slot,
+                         uint32_t *count, uint32_t *flags, int nb);
+void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
+                             const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb);
+void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb);
+// read-back helpers
+void launch_unsort_particles(hipStream_t st, const Consts &c, const Arrays &a, int n, sph_particle *out_dev);
+void launch_unsort_accel(hipStream_t st, const Arrays &a, int n, float *du, float *dv);
+void launch_unsort_boundary(hipStream_t st, const Consts &c, const Arrays &a, int nb, sph_particle *out_dev);
+void launch_upload_state(hipStream_t st, const Arrays &a, int n, const sph_particle *in_dev);
+void launch_gather_rho_p(hipStream_t st, const Consts &c, const Arrays &a, int n, const sph_particle *in_dev);
+void launch_stats(hipStream_t st, const Arrays &a, int n);
+void launch_metaballs(hipStream_t st, const Consts &c, const Arrays &a, float width, float height,
+                      unsigned char *bits_dev /* 8192 bytes, one per pixel */);
+
+}  // namespace sph

@@ -1,0 +1,588 @@
+// sph_kernels.hip — hand-written gfx950 kernels of the 2-D WCSPH step.
+//
+// What each kernel restates (file = /root/reference/pi_sph_fluid.c):
+//   k_kick_drift_key   kick 1/2 + drift :615-624, cell index :111-113, histogram (counting sort pass 1)
+//   k_scan_*           exclusive scan of the cell histogram (counting sort pass 2)
+//   k_reorder          scatter into cell-contiguous order (replaces the linked list :104-124)
+//   k_density_*        calculate_density :263-289 (+ calculate_particle_pressure :294-301 when fused)
+//   k_force_*          calculate_accelerations :303-373 (+ kick 1/2 :637-640 when fused)
+//   k_boundary_psi     calculate_boundary_pseudomass :242-261
+//
+// Data layout: SoA, cell-sorted every step.  Cells are linearised column-major
+// (cell = col*rows + row), so the 3x3 neighbourhood of a particle is THREE contiguous ranges
+// of the sorted arrays (one per column: rows r-1..r+1).  No MFMA anywhere: there is no dense
+// contraction in this workload; the kernels are HBM/LDS/VALU work.
+#include "sph_internal.h"
+
+namespace sph {
+
+#define DEV __device__ __forceinline__
+
+constexpr int BLK = 256;   // 4 waves of 64
+
+DEV bool finite_bits(float x) { return (__float_as_uint(x) & 0x7fffffffu) < 0x7f800000u; }
+
+// cell of a position, clamped into the grid. Same arithmetic as :111-112 (true division,
+// truncation toward zero); out-of-range and NaN are reported through `oob` / `bad`.
+DEV void cell_of(const Consts &c, float x, float y, int &row, int &col, bool &oob, bool &bad) {
+    bad = !(finite_bits(x) && finite_bits(y));
+    float fr = (y - c.y_min) / c.cell, fc = (x - c.x_min) / c.cell;
+    row = bad ? 0 : (int)fr;
+    col = bad ? 0 : (int)fc;
+    oob = (fr < 0.0f) | (fc < 0.0f) | (row >= c.rows) | (col >= c.cols);
+    row = min(max(row, 0), c.rows - 1);
+    col = min(max(col, 0), c.cols - 1);
+}
+
+// Wendland C2 without its normalising factor: (1 - q/2)^4 (1 + 2q), q = d/H   (:45-50)
+DEV float w_shape(const Consts &c, float d2) {
+    float d = __builtin_amdgcn_sqrtf(d2);
+    float q = d * c.inv_h;
+    float a = fmaf(-0.5f, q, 1.0f);
+    float a2 = a * a;
+    return a2 * a2 * fmaf(2.0f, q, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// gravity lives in device memory so that a captured step graph can be replayed under a
+// changing gravity vector (the reference re-reads g every step, :632)
+__global__ void k_set_gravity(float2 *grav, float gx, float gy) { *grav = make_float2(gx, gy); }
+
+void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy) {
+    hipLaunchKernelGGL(k_set_gravity, dim3(1), dim3(1), 0, st, a.grav, gx, gy);
+}
+
+// ------------------------------------------------------------------------------------------
+// P1: kick 1/2 + drift + key + histogram.  44 B/particle + 4 B slot.
+template <bool INTEGRATE>
+__global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *__restrict__ pos,
+                                                        const uint32_t *__restrict__ id, const float2 *__restrict__ acc,
+                                                        float2 *__restrict__ velt, float4 *__restrict__ pk,
+                                                        uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
+                                                        uint32_t *__restrict__ flags, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    float2 p = pos[i];
+    if (INTEGRATE) {
+        float2 v = velt[i];
+        float2 a = acc[i];
+        v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
+        v.y = fmaf(c.half_dt, a.y, v.y);
+        p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
+        p.y = fmaf(c.dt, v.y, p.y);
+        velt[i] = v;
+    }
+    int row, col;
+    bool oob, bad;
+    cell_of(c, p.x, p.y, row, col, oob, bad);
+    uint32_t key = (uint32_t)(col * c.rows + row);
+    pk[i] = make_float4(p.x, p.y, __uint_as_float(id[i]), __uint_as_float(key));
+    slot[i] = atomicAdd(&count[key], 1u);
+    if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
+    else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
+}
+
+void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_kick_drift_key<true>, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.id, a.acc,
+                       a.velt, a.pk, a.slot, a.count, a.flags, n);
+}
+void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_kick_drift_key<false>, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.id, a.acc,
+                       a.velt, a.pk, a.slot, a.count, a.flags, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// P2/P3: exclusive scan over n_cells+1 histogram entries (padded to SCAN_TILE with zeros).
+DEV uint32_t wave_incl_scan(uint32_t v) {
+    int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+DEV uint32_t block_sum_256(uint32_t v, uint32_t *lds4) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds4[w] = v;
+    __syncthreads();
+    uint32_t t = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__restrict__ count,
+                                                            uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t red[4];
+    const uint4 *src = reinterpret_cast<const uint4 *>(count + (size_t)blockIdx.x * SCAN_TILE) + threadIdx.x * 2;
+    uint4 a = src[0], b = src[1];
+    uint32_t s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict__ count,
+                                                           const uint32_t *__restrict__ block_sums,
+                                                           uint32_t *__restrict__ cell_start, int n_items) {
+    __shared__ uint32_t red[4];
+    __shared__ uint32_t wave_tot[4];
+    // offset of this tile = sum of the tiles before it (<= a few thousand L2-resident words)
+    uint32_t off = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_BLOCK) off += block_sums[k];
+    off = block_sum_256(off, red);
+
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint4 *src = reinterpret_cast<uint4 *>(count + base);
+    uint4 a = src[0], b = src[1];
+    uint32_t v[SCAN_ITEMS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) tsum += v[k];
+    uint32_t incl = wave_incl_scan(tsum);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wave_tot[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) woff += (k < w) ? wave_tot[k] : 0u;
+    uint32_t run = off + woff + incl - tsum;
+    // the histogram is consumed: leave it zeroed for the next sort
+    src[0] = make_uint4(0, 0, 0, 0);
+    src[1] = make_uint4(0, 0, 0, 0);
+    uint32_t o[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { o[k] = run; run += v[k]; }
+    if (base + SCAN_ITEMS <= (size_t)n_items) {
+        uint4 *dst = reinterpret_cast<uint4 *>(cell_start + base);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++)
+            if (base + k < (size_t)n_items) cell_start[base + k] = o[k];
+    }
+}
+
+void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *cell_start, uint32_t *block_sums,
+                 hipEvent_t mid) {
+    int n_items = c.n_cells + 1;
+    int tiles = (n_items + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums);
+    if (mid) (void)hipEventRecord(mid, st);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums, cell_start, n_items);
+}
+
+// ------------------------------------------------------------------------------------------
+// P4: scatter to cell order.
+__global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, const float2 *__restrict__ velt,
+                                                 const uint32_t *__restrict__ slot,
+                                                 const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
+                                                 float2 *__restrict__ vel, uint32_t *__restrict__ id, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    float4 q = pk[i];
+    uint32_t dst = cell_start[__float_as_uint(q.w)] + slot[i];
+    pos[dst] = make_float2(q.x, q.y);
+    vel[dst] = velt[i];
+    id[dst] = __float_as_uint(q.z);
+}
+
+void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int n) {
+    (void)c;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_reorder, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, a.pk, a.velt, a.slot, a.cell_start, a.pos,
+                       a.vel, a.id, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// Tait EOS, clamped at zero (:294-301): p = max(0, B((rho/rho0)^7 - 1)); also p/rho^2 for the force pass.
+DEV void eos(const Consts &c, float rho, float &p, float &p_over_rho2) {
+    float r = rho / c.rho0;
+    float r2 = r * r, r4 = r2 * r2;
+    float r7 = r4 * r2 * r;
+    p = fmaxf(c.B * (r7 - 1.0f), 0.0f);
+    p_over_rho2 = p / (rho * rho);
+}
+
+// ------------------------------------------------------------------------------------------
+// P5 (variant 1, "direct"): one thread per particle, neighbours read straight from the sorted
+// arrays through L1/L2.
+template <bool EOS>
+__global__ __launch_bounds__(BLK) void k_density_direct(Consts c, const float2 *__restrict__ pos,
+                                                        const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
+                                                        const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
+                                                        float2 *__restrict__ rp, float *__restrict__ prs, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    float2 pi = pos[i];
+    int row, col;
+    bool oob, bad;
+    cell_of(c, pi.x, pi.y, row, col, oob, bad);
+    int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
+    float sf = 0.0f, sb = 0.0f;
+    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
+        int base = cc * c.rows;
+        uint32_t beg = cs[base + r0], end = cs[base + r1 + 1];
+        for (uint32_t j = beg; j < end; j++) {      // includes j == i: W(0) = nf is the self term of :274-275
+            float2 pj = pos[j];
+            float dx = pi.x - pj.x, dy = pi.y - pj.y;
+            float d2 = fmaf(dx, dx, dy * dy);
+            float w = w_shape(c, d2);
+            sf += (d2 < c.cut2) ? w : 0.0f;
+        }
+        uint32_t bbeg = bcs[base + r0], bend = bcs[base + r1 + 1];
+        for (uint32_t j = bbeg; j < bend; j++) {
+            float2 pj = bpos[j];
+            float dx = pi.x - pj.x, dy = pi.y - pj.y;
+            float d2 = fmaf(dx, dx, dy * dy);
+            float w = w_shape(c, d2) * bpsi[j];
+            sb += (d2 < c.cut2) ? w : 0.0f;
+        }
+    }
+    float rho = c.nf * fmaf(c.m_fluid, sf, sb);     // m W(0) + sum m W + sum psi W   :287
+    if (EOS) {
+        float p, pr2;
+        eos(c, rho, p, pr2);
+        rp[i] = make_float2(rho, pr2);
+        prs[i] = p;
+    } else {
+        rp[i].x = rho;
+    }
+}
+
+// EOS alone (stage entry point): from the stored rho, or (from_prs) only refresh p/rho^2 from stored rho and p
+template <bool FROM_PRS>
+__global__ __launch_bounds__(BLK) void k_eos(Consts c, float2 *__restrict__ rp, float *__restrict__ prs, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    float rho = rp[i].x;
+    if (FROM_PRS) {
+        rp[i].y = prs[i] / (rho * rho);
+    } else {
+        float p, pr2;
+        eos(c, rho, p, pr2);
+        rp[i].y = pr2;
+        prs[i] = p;
+    }
+}
+
+void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int n, bool from_prs) {
+    if (n <= 0) return;
+    dim3 g((n + BLK - 1) / BLK), b(BLK);
+    if (from_prs) hipLaunchKernelGGL(k_eos<true>, g, b, 0, st, c, a.rp, a.prs, n);
+    else hipLaunchKernelGGL(k_eos<false>, g, b, 0, st, c, a.rp, a.prs, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// pair term of calculate_accelerations (:317-337 / :346-365) on squared distance.
+//   returns coef such that  -(m_j temp_ij grad_i W_ij) = grad_c * m_j * coef * (dx,dy)
+//   (grad_i W_ij = -5 nf (1-q/2)^3 (dx,dy)/H^2 because q/d = 1/H, :56-59)
+DEV float pair_coef(const Consts &c, float d2, float xv, float pr_sum, float rho_mean) {
+    float d = __builtin_amdgcn_sqrtf(d2);
+    float q = d * c.inv_h;
+    float a = fmaf(-0.5f, q, 1.0f);
+    float a2 = a * a;
+    float a3 = a2 * a;
+    float w = a3 * a * fmaf(2.0f, q, 1.0f);                  // W_ij / nf            :324
+    float s = w * (c.nf * c.inv_w_k2h);                       // W_ij / W(0.2H)
+    float s2 = s * s;
+    float art = c.k1 * s2 * s2;                               // artificial pressure  :325
+    float inv = __builtin_amdgcn_rcpf((d2 + c.eps_h2) * rho_mean);
+    float visc = (xv < 0.0f) ? -c.visc_c * xv * inv : 0.0f;   // artificial viscosity :332-334
+    return a3 * (pr_sum + art + visc);                        // temp_ij * (1-q/2)^3  :336
+}
+
+// P6 (variant 1, "direct")
+template <bool KICK>
+__global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__restrict__ pos,
+                                                      const float2 *__restrict__ vel, const float2 *__restrict__ rp,
+                                                      const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
+                                                      const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
+                                                      const float2 *__restrict__ grav, float2 *__restrict__ acc,
+                                                      float2 *__restrict__ velt, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    float2 pi = pos[i], vi = vel[i], rpi = rp[i];
+    int row, col;
+    bool oob, bad;
+    cell_of(c, pi.x, pi.y, row, col, oob, bad);
+    int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
+    float fx = 0.0f, fy = 0.0f, bx = 0.0f, by = 0.0f;
+    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
+        int base = cc * c.rows;
+        uint32_t beg = cs[base + r0], end = cs[base + r1 + 1];
+        for (uint32_t j = beg; j < end; j++) {
+            float2 pj = pos[j];
+            float dx = pi.x - pj.x, dy = pi.y - pj.y;
+            float d2 = fmaf(dx, dx, dy * dy);
+            // j == i and coincident particles (d = 0, 0/0 in the reference :58-59) exert no force
+            if (d2 < c.cut2 && d2 > 0.0f) {
+                float2 vj = vel[j], rpj = rp[j];
+                float xv = fmaf(dx, vi.x - vj.x, dy * (vi.y - vj.y));              // :330
+                float cf = pair_coef(c, d2, xv, rpi.y + rpj.y, 0.5f * (rpi.x + rpj.x));
+                fx = fmaf(cf, dx, fx);
+                fy = fmaf(cf, dy, fy);
+            }
+        }
+        uint32_t bbeg = bcs[base + r0], bend = bcs[base + r1 + 1];
+        for (uint32_t j = bbeg; j < bend; j++) {
+            float2 pj = bpos[j];
+            float dx = pi.x - pj.x, dy = pi.y - pj.y;
+            float d2 = fmaf(dx, dx, dy * dy);
+            if (d2 < c.cut2 && d2 > 0.0f) {
+                float xv = fmaf(dx, vi.x, dy * vi.y);                              // boundary velocity = 0 :357
+                float cf = bpsi[j] * pair_coef(c, d2, xv, rpi.y, rpi.x);           // :350, :362
+                bx = fmaf(cf, dx, bx);
+                by = fmaf(cf, dy, by);
+            }
+        }
+    }
+    float2 g = *grav;
+    float ax = fmaf(c.grad_c, fmaf(c.m_fluid, fx, bx), g.x);                       // :370
+    float ay = fmaf(c.grad_c, fmaf(c.m_fluid, fy, by), g.y);                       // :371
+    acc[i] = make_float2(ax, ay);
+    if (KICK) velt[i] = make_float2(fmaf(c.half_dt, ax, vi.x), fmaf(c.half_dt, ay, vi.y));   // :638-639
+}
+
+}  // namespace sph
+
+#include "sph_tiled.inc"
+
+namespace sph {
+
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int n, bool with_eos, int variant) {
+    if (n <= 0) return;
+    if (variant == 0) { launch_density_tiled(st, c, a, n, with_eos); return; }
+    dim3 g((n + BLK - 1) / BLK), b(BLK);
+    if (with_eos)
+        hipLaunchKernelGGL(k_density_direct<true>, g, b, 0, st, c, a.pos, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
+                           a.rp, a.prs, n);
+    else
+        hipLaunchKernelGGL(k_density_direct<false>, g, b, 0, st, c, a.pos, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
+                           a.rp, a.prs, n);
+}
+
+void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int n, bool kick, int variant) {
+    if (n <= 0) return;
+    if (variant == 0) { launch_force_tiled(st, c, a, n, kick); return; }
+    dim3 g((n + BLK - 1) / BLK), b(BLK);
+    if (kick)
+        hipLaunchKernelGGL(k_force_direct<true>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.cell_start, a.bpos, a.bpsi,
+                           a.bcell_start, a.grav, a.acc, a.velt, n);
+    else
+        hipLaunchKernelGGL(k_force_direct<false>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.cell_start, a.bpos, a.bpsi,
+                           a.bcell_start, a.grav, a.acc, a.velt, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// boundary: bin once (:600) and Akinci pseudo-mass (:242-261)
+__global__ __launch_bounds__(BLK) void k_boundary_key(Consts c, const float2 *__restrict__ bpos_in,
+                                                      uint32_t *__restrict__ key, uint32_t *__restrict__ slot,
+                                                      uint32_t *__restrict__ count, uint32_t *__restrict__ flags, int nb) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= nb) return;
+    float2 p = bpos_in[i];
+    int row, col;
+    bool oob, bad;
+    cell_of(c, p.x, p.y, row, col, oob, bad);
+    uint32_t k = (uint32_t)(col * c.rows + row);
+    key[i] = k;
+    slot[i] = atomicAdd(&count[k], 1u);
+    if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
+    else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
+}
+
+__global__ __launch_bounds__(BLK) void k_boundary_reorder(const float2 *__restrict__ bpos_in,
+                                                          const uint32_t *__restrict__ key,
+                                                          const uint32_t *__restrict__ slot,
+                                                          const uint32_t *__restrict__ cell_start,
+                                                          float2 *__restrict__ bpos, uint32_t *__restrict__ bid, int nb) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= nb) return;
+    uint32_t dst = cell_start[key[i]] + slot[i];
+    bpos[dst] = bpos_in[i];
+    bid[dst] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(BLK) void k_boundary_psi(Consts c, const float2 *__restrict__ bpos,
+                                                      const uint32_t *__restrict__ bcs, float *__restrict__ bpsi, int nb) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= nb) return;
+    float2 pi = bpos[i];
+    int row, col;
+    bool oob, bad;
+    cell_of(c, pi.x, pi.y, row, col, oob, bad);
+    int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
+    float s = 0.0f;
+    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
+        int base = cc * c.rows;
+        uint32_t beg = bcs[base + r0], end = bcs[base + r1 + 1];
+        for (uint32_t j = beg; j < end; j++) {
+            float2 pj = bpos[j];
+            float dx = pi.x - pj.x, dy = pi.y - pj.y;
+            float d2 = fmaf(dx, dx, dy * dy);
+            // self excluded by index (:130,:144); a coincident duplicate (d = 0) does count, W = nf
+            if (j != (uint32_t)i && d2 < c.cut2) s += w_shape(c, d2);
+        }
+    }
+    bpsi[i] = c.rho0 / (c.nf * s);      // psi = rho_0 / sum W   :259
+}
+
+void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in, uint32_t *key, uint32_t *slot,
+                         uint32_t *count, uint32_t *flags, int nb) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_boundary_key, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, c, bpos_in, key, slot, count, flags, nb);
+}
+void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
+                             const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_boundary_reorder, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, bpos_in, key, slot, cell_start,
+                       bpos, bid, nb);
+}
+void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_boundary_psi, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.bpos, a.bcell_start, a.bpsi, nb);
+}
+
+// ------------------------------------------------------------------------------------------
+// read-back / upload helpers (original particle order <-> cell order through the carried id)
+__global__ __launch_bounds__(BLK) void k_unsort_particles(Consts c, const float2 *__restrict__ pos,
+                                                          const float2 *__restrict__ velt,
+                                                          const uint32_t *__restrict__ id, const float2 *__restrict__ rp,
+                                                          const float *__restrict__ prs, sph_particle *__restrict__ out,
+                                                          int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    float2 p = pos[i], v = velt[i];
+    sph_particle q;
+    q.x = p.x; q.y = p.y; q.u = v.x; q.v = v.y; q.m = c.m_fluid; q.rho = rp[i].x; q.p = prs[i];
+    out[id[i]] = q;
+}
+__global__ __launch_bounds__(BLK) void k_unsort_accel(const float2 *__restrict__ acc, const uint32_t *__restrict__ id,
+                                                      float *__restrict__ du, float *__restrict__ dv, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    float2 a = acc[i];
+    uint32_t k = id[i];
+    du[k] = a.x;
+    dv[k] = a.y;
+}
+__global__ __launch_bounds__(BLK) void k_unsort_boundary(Consts c, const float2 *__restrict__ bpos,
+                                                         const float *__restrict__ bpsi, const uint32_t *__restrict__ bid,
+                                                         sph_particle *__restrict__ out, int nb) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= nb) return;
+    sph_particle q;
+    q.x = bpos[i].x; q.y = bpos[i].y; q.u = 0; q.v = 0; q.m = bpsi[i]; q.rho = c.rho0; q.p = 0;
+    out[bid[i]] = q;
+}
+__global__ __launch_bounds__(BLK) void k_upload_state(const sph_particle *__restrict__ in, float2 *__restrict__ pos,
+                                                      float2 *__restrict__ velt, uint32_t *__restrict__ id, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    sph_particle q = in[i];
+    pos[i] = make_float2(q.x, q.y);
+    velt[i] = make_float2(q.u, q.v);
+    id[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(BLK) void k_gather_rho_p(const sph_particle *__restrict__ in, const uint32_t *__restrict__ id,
+                                                      float2 *__restrict__ rp, float *__restrict__ prs, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    sph_particle q = in[id[i]];
+    rp[i] = make_float2(q.rho, q.p / (q.rho * q.rho));
+    prs[i] = q.p;
+}
+
+void launch_unsort_particles(hipStream_t st, const Consts &c, const Arrays &a, int n, sph_particle *out_dev) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_unsort_particles, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.velt, a.id, a.rp, a.prs,
+                       out_dev, n);
+}
+void launch_unsort_accel(hipStream_t st, const Arrays &a, int n, float *du, float *dv) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_unsort_accel, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, a.acc, a.id, du, dv, n);
+}
+void launch_unsort_boundary(hipStream_t st, const Consts &c, const Arrays &a, int nb, sph_particle *out_dev) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_unsort_boundary, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.bpos, a.bpsi, a.bid, out_dev, nb);
+}
+void launch_upload_state(hipStream_t st, const Arrays &a, int n, const sph_particle *in_dev) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_upload_state, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, in_dev, a.pos, a.velt, a.id, n);
+}
+void launch_gather_rho_p(hipStream_t st, const Consts &c, const Arrays &a, int n, const sph_particle *in_dev) {
+    (void)c;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_rho_p, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, in_dev, a.id, a.rp, a.prs, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// statistics of :657-671 as device max-reductions (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(BLK) void k_stats(const float2 *__restrict__ rp, const float2 *__restrict__ velt,
+                                               uint32_t *__restrict__ flags, int n) {
+    float mr = 0.0f, ms = 0.0f;
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        mr = fmaxf(mr, rp[i].x);
+        float2 v = velt[i];
+        ms = fmaxf(ms, fmaf(v.x, v.x, v.y * v.y));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mr = fmaxf(mr, __shfl_xor(mr, d, 64));
+        ms = fmaxf(ms, __shfl_xor(ms, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&flags[FLAG_MAXRHO], __float_as_uint(fmaxf(mr, 0.0f)));
+        atomicMax(&flags[FLAG_MAXSPEED], __float_as_uint(sqrtf(ms)));
+    }
+}
+void launch_stats(hipStream_t st, const Arrays &a, int n) {
+    if (n <= 0) return;
+    int blocks = min((n + BLK - 1) / BLK, 2048);
+    hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(BLK), 0, st, a.rp, a.velt, a.flags, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// metaballs (:380-411): one thread per pixel of the 128x64 panel, pixel centres as :573
+__global__ __launch_bounds__(BLK) void k_metaballs(Consts c, const float2 *__restrict__ pos,
+                                                   const uint32_t *__restrict__ cs, float width, float height,
+                                                   float inv_w_half_px, unsigned char *__restrict__ bits) {
+    int ij = blockIdx.x * BLK + threadIdx.x;
+    if (ij >= 64 * 128) return;
+    int i = ij / 128, j = ij % 128;
+    float px = c.x_min + (float)((j + 0.5) * (double)width / 128.0);
+    float py = c.y_min + (float)((64 - (i + 0.5)) * (double)height / 64.0);
+    int row, col;
+    bool oob, bad;
+    cell_of(c, px, py, row, col, oob, bad);
+    int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
+    float s = 0.0f;
+    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
+        int base = cc * c.rows;
+        uint32_t beg = cs[base + r0], end = cs[base + r1 + 1];
+        for (uint32_t k = beg; k < end; k++) {
+            float2 pj = pos[k];
+            float dx = px - pj.x, dy = py - pj.y;
+            float d2 = fmaf(dx, dx, dy * dy);
+            if (d2 < c.cut2) s += w_shape(c, d2);
+        }
+    }
+    bits[ij] = (s * c.nf * inv_w_half_px >= 1.0f) ? 1 : 0;     // sum W / W(px/2) >= 1   :401-407
+}
+void launch_metaballs(hipStream_t st, const Consts &c, const Arrays &a, float width, float height, unsigned char *bits_dev) {
+    // W(px_width/2) with px_width = WIDTH/128 (:399-401), evaluated like the device W
+    float half_px = width / 128.0f / 2.0f;
+    float q = half_px / c.h;
+    float t = 1.0f - 0.5f * q;
+    float w = c.nf * (t * t) * (t * t) * (1.0f + 2.0f * q);
+    hipLaunchKernelGGL(k_metaballs, dim3(64 * 128 / BLK), dim3(BLK), 0, st, c, a.pos, a.cell_start, width, height, 1.0f / w,
+                       bits_dev);
+}
+
+}  // namespace sph

@@ -1,0 +1,122 @@
+"""Host logic and the C-ABI surface, CPU only: scene generators, gravity sources, exported symbols,
+and the "no GPU => loud failure" contract."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits_equal, load_golden
+
+
+def test_abi_library_loads_and_exports_every_declared_symbol(sph):
+    L = C.CDLL(sph.LIB_HIP)
+    header = open(os.path.join(ROOT, "include", "sph.h")).read()
+    declared = set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", header)) - {"sph_ctx"}
+    assert declared == set(sph.ABI_SYMBOLS), declared ^ set(sph.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    H = C.CDLL(sph.LIB_HOST)
+    hheader = open(os.path.join(ROOT, "include", "sph_host.h")).read()
+    hdecl = set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", hheader))
+    for name in hdecl:
+        assert hasattr(H, name), name
+    assert L.sph_abi_version() == 1
+
+
+def test_struct_layouts(sph):
+    assert sph.PARTICLE.itemsize == 28                       # struct particle :26-31
+    assert C.sizeof(sph.Params) == 15 * 4
+    assert C.sizeof(sph.KernelTimes) == 7 * 4 + 4 + 4
+
+
+def test_default_params_bit_patterns(sph):
+    p = sph.default_params()
+    g = load_golden("drop.npz")["constants"]
+    got = np.array([p.r, p.h, p.x_max - p.x_min, p.y_max - p.y_min, p.rho0, p.c, p.g, p.dt, p.vol], np.float32)
+    assert bits_equal(got, g[:9])
+    hp = sph.Params()
+    sph.hip_lib().sph_params_default(C.byref(hp))
+    assert bytes(hp) == bytes(p)
+
+
+def test_default_scene_matches_reference(sph):
+    g = load_golden("drop.npz")
+    prm, f, b = sph.scene("cfg0")
+    assert len(f) == 269 and len(b) == 162
+    assert bits_equal(np.stack([f["x"], f["y"]], 1), g["fluid_xy0"])
+    assert bits_equal(np.stack([b["x"], b["y"]], 1), g["boundary_xy"])
+    assert np.all(f["rho"] == 1000) and np.all(f["u"] == 0) and np.all(b["m"] == 0)
+    assert bits_equal(f["m"], np.full(269, np.float32(prm.rho0) * np.float32(prm.vol), np.float32))
+
+
+def test_block_scene_matches_fixture(sph):
+    g = load_golden("block.npz")
+    prm, f, b = sph.scene_block(tuple(g["box"]), 0.3, 0.3, 240, 60)
+    assert bits_equal(np.stack([f["x"], f["y"]], 1), g["fluid_xy0"])
+    assert bits_equal(np.stack([b["x"], b["y"]], 1), g["boundary_xy"])
+
+
+def test_config_sizes(sph):
+    """SURVEY.md §8d concrete configs."""
+    prm, f, b = sph.scene("cfg1")
+    assert len(f) == 262144 and len(b) == 16386
+    # all inside the box, >= 4R from the walls, lattice spacing R
+    assert f["x"].min() > 0.3 and f["y"].min() > 0.3 and f["y"].max() < 204.8
+    prm, f, b = sph.scene_block((0.0, 120.0, 0.0, 60.0), 0.3, 0.3, 400, 500)
+    assert len(f) == 200000 and abs(float(f["x"][500] - f["x"][0]) - 0.075) < 1e-6
+    assert len(sph.dam_break(1)[2]) == 33600
+
+
+def test_scene_capacity_errors(sph):
+    p = sph.default_params()
+    buf = np.zeros(10, sph.PARTICLE)
+    L = sph.host_lib()
+    assert L.sph_scene_default_fluid(C.byref(p), buf.ctypes.data_as(C.c_void_p), 10) == sph.SPH_E_ARG
+    assert L.sph_scene_walls(C.byref(p), 1, buf.ctypes.data_as(C.c_void_p), 10) == sph.SPH_E_ARG
+    assert L.sph_scene_block(C.byref(p), 0.3, 0.3, 4, 4, buf.ctypes.data_as(C.c_void_p), 10) == sph.SPH_E_ARG
+    assert L.sph_scene_block(C.byref(p), 0.3, 0.3, -1, 4, None, 0) == sph.SPH_E_ARG
+
+
+def test_gravity_sources(sph, tmp_path):
+    gs = sph.GravitySource(sph.GRAVITY_CONSTANT, 9.81)
+    assert gs.sample(0.0) == (0.0, pytest.approx(-9.81))                    # :442-443
+    tilt = sph.GravitySource(sph.GRAVITY_TILT, 9.81)
+    gx0, gy0 = tilt.sample(0.0)
+    assert gx0 == pytest.approx(0.0, abs=1e-7) and gy0 == pytest.approx(-9.81)
+    assert tilt.sample(0.05) == (gx0, gy0)                                  # zero-order hold, 10 Hz (:459)
+    gx2, gy2 = tilt.sample(2.0)                                             # quarter period: theta = 15 deg
+    assert gx2 == pytest.approx(9.81 * np.sin(np.radians(15)), rel=1e-6)
+    assert gy2 == pytest.approx(-9.81 * np.cos(np.radians(15)), rel=1e-6)
+    # MPU6050 sysfs reader with the axis mapping of :439-440
+    (tmp_path / "in_accel_x_raw").write_text("8192\n")
+    (tmp_path / "in_accel_y_raw").write_text("-16384\n")
+    mpu = sph.GravitySource(sph.GRAVITY_MPU6050, 9.81, sysfs_dir=str(tmp_path))
+    gx, gy = mpu.sample(0.0)
+    assert gx == pytest.approx(-9.81) and gy == pytest.approx(-0.5 * 9.81)
+    bad = sph.GravitySource(sph.GRAVITY_MPU6050, 9.81, sysfs_dir=str(tmp_path / "missing"))
+    with pytest.raises(sph.SphError):
+        bad.sample(0.0)
+
+
+def test_create_argument_errors_and_no_cpu_fallback(sph):
+    prm, f, b = sph.scene("cfg0")
+    L = sph.hip_lib()
+    h = C.c_void_p()
+    assert L.sph_create(None, C.byref(prm), None, 0, None, 0, 0.0, -9.81, 0) == sph.SPH_E_ARG
+    rc = L.sph_create(C.byref(h), C.byref(prm), None, 5, None, 0, 0.0, -9.81, 0)
+    assert rc == sph.SPH_E_ARG and b"null" in L.sph_last_error(h)
+    L.sph_destroy(h)
+    f2 = f.copy()
+    f2["m"][3] *= 2
+    with pytest.raises(sph.SphError) as e:
+        sph.Context(prm, f2, b)
+    assert e.value.code == sph.SPH_E_ARG
+    if L.sph_device_count() == 0:
+        # the product path must fail loudly without a GPU — there is no CPU fallback
+        with pytest.raises(sph.SphError) as e:
+            sph.Context(prm, f, b)
+        assert e.value.code == sph.SPH_E_HIP
+    assert L.sph_error_string(sph.SPH_E_HIP).decode().startswith("HIP failure")
+    assert L.sph_step(None, 0.0, 0.0, 1) == sph.SPH_E_ARG
