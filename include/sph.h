@@ -134,6 +134,10 @@ int  sph_eval_accel(sph_ctx *ctx, float gx, float gy);     /* calculate_accelera
 /* ---- measurement ---- */
 /* run nsteps steps eagerly with HIP events around every kernel (same kernels as sph_step) */
 int  sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_times *out);
+/* mean device time [ms] of `reps` back-to-back launches of ONE per-step kernel on the live state, between two HIP
+ * events on the context's stream.  Only the idempotent kernels (SPH_K_DENSITY_EOS, SPH_K_FORCE_KICK: same
+ * inputs -> same outputs, nothing they read is overwritten) can be timed this way; others give SPH_E_ARG. */
+int  sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms);
 /* adopt an existing hipStream_t (e.g. the host framework's current stream); NULL = own stream */
 int  sph_set_stream(sph_ctx *ctx, void *hip_stream);
 /* device bytes held by the context */

@@ -48,6 +48,13 @@ def outputs(R, fluid, boundary, box):
     return f["rho"].copy(), f["p"].copy(), du, dv
 
 
+def adev(du, dv, edu, edv):
+    """acceleration deviation figures of gate G4: max |da| and rms|da| / rms|a|."""
+    da = np.hypot(du.astype(np.float64) - edu, dv.astype(np.float64) - edv)
+    rms_a = np.sqrt(np.mean(edu.astype(np.float64) ** 2 + edv.astype(np.float64) ** 2))
+    return {"a_abs": float(da.max()), "a_rms_rel": float(np.sqrt(np.mean(da ** 2)) / rms_a)}
+
+
 def dev(a, b):
     a64, b64 = a.astype(np.float64), b.astype(np.float64)
     d = np.abs(a64 - b64)
@@ -97,7 +104,7 @@ def main():
         g = f.copy()
         gdu, gdv = RF.eval(g, b, box, GX, GY, flags=7, threads=4)
         self_dev["k%d" % k] = {"rho": dev(f["rho"], g["rho"]), "p": dev(f["p"], g["p"]),
-                               "a_abs": float(np.hypot(gdu - data["eval_du_%d" % k], gdv - data["eval_dv_%d" % k]).max()),
+                               **adev(gdu, gdv, data["eval_du_%d" % k], data["eval_dv_%d" % k]),
                                "traj_dx_fast_vs_strict": float(max(np.abs(ff["x"] - f["x"]).max(), np.abs(ff["y"] - f["y"]).max()))}
     assert maxn[0] <= 48 and maxn[1] <= 48, maxn
     np.savez_compressed(os.path.join(OUT, "drop.npz"), **data)
@@ -131,7 +138,7 @@ def main():
                                          "p_max": float(f["p"].max()),
                                          "speed_max": float(np.hypot(f["u"], f["v"]).max()),
                                          "fast_vs_strict": {"rho": dev(f["rho"], g["rho"]), "p": dev(f["p"], g["p"]),
-                                                            "a_abs": float(np.hypot(gdu - edu, gdv - edv).max())}}
+                                                            **adev(gdu, gdv, edu, edv)}}
 
     # ---------------- gas: random positions / velocities ----------------
     bx = (0.0, 6.0, 0.0, 6.0)
@@ -153,10 +160,15 @@ def main():
     mn = R.max_neighbors(f, b, box)
     assert mn[0] <= 48 and mn[1] <= 48, mn
     rho, p, du, dv = outputs(R, f, b, box)
+    g = f.copy()
+    RF.psi(b.copy(), box)
+    gdu, gdv = RF.eval(g, b, box, GX, GY, flags=7, threads=4)
+    gas_self = {"rho": dev(rho, g["rho"]), "p": dev(p, g["p"]), **adev(gdu, gdv, du, dv)}
     np.savez_compressed(os.path.join(OUT, "gas.npz"), boundary_xy=np.stack([b["x"], b["y"]], 1), psi=b["m"].copy(),
                         state=state_of(f), rho=rho, p=p, eval_du=du, eval_dv=dv, box=np.array(bx, np.float32))
     manifest["fixtures"]["gas.npz"] = {"n_fluid": n, "n_boundary": len(b), "box": list(bx), "seed": seed,
-                                       "max_neighbors": mn, "rho_range": [float(rho.min()), float(rho.max())]}
+                                       "max_neighbors": mn, "rho_range": [float(rho.min()), float(rho.max())],
+                                       "fast_vs_strict": gas_self}
 
     for name in list(manifest["fixtures"]):
         with open(os.path.join(OUT, name), "rb") as fh:

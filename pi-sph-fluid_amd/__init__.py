@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_out_of_domain_count",
     "sph_upload_state", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
-    "sph_profile_steps", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
+    "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
     "sph_render_metaballs",
 ]
 HOST_SYMBOLS = [
@@ -118,6 +118,7 @@ def hip_lib():
         L.sph_eval_pressure.argtypes = [vp]
         L.sph_eval_accel.argtypes = [vp, cf, cf]
         L.sph_profile_steps.argtypes = [vp, cf, cf, ci, C.POINTER(KernelTimes)]
+        L.sph_time_kernel.argtypes = [vp, ci, ci, C.POINTER(cf)]
         L.sph_set_stream.argtypes = [vp, vp]
         L.sph_device_bytes.argtypes = [vp]
         L.sph_device_bytes.restype = C.c_size_t
@@ -317,6 +318,12 @@ class Context:
         d = {KERNEL_NAMES[k]: kt.ms[k] for k in range(6)}
         d["step"] = kt.step_ms
         return d
+
+    def time_kernel(self, name, reps=20):
+        """mean ms per launch of an idempotent kernel ('density_eos' or 'force_kick'), back-to-back launches."""
+        ms = C.c_float()
+        self._chk(self.L.sph_time_kernel(self.h, KERNEL_NAMES.index(name), reps, C.byref(ms)))
+        return ms.value
 
     def set_stream(self, hip_stream):
         self._chk(self.L.sph_set_stream(self.h, C.c_void_p(hip_stream)))

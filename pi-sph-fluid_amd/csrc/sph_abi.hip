@@ -97,6 +97,7 @@ int make_consts(const sph_params &p, Consts &c) {
     c.x_min = p.x_min;
     c.y_min = p.y_min;
     c.cell = 2 * p.h;                                                    // :596
+    c.inv_cell = 1.0f / c.cell;
     double rows = (double)(int)((p.y_max - p.y_min) / c.cell) + 1;       // :93
     double cols = (double)(int)((p.x_max - p.x_min) / c.cell) + 1;       // :94
     if (rows * cols > 1.0e9) return SPH_E_ARG;
@@ -121,7 +122,7 @@ void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
     if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
     launch_reorder(st, ctx->c, ctx->a, ctx->n);
     if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
-    launch_density(st, ctx->c, ctx->a, ctx->n, true, ctx->variant);
+    launch_density(st, ctx->c, ctx->a, ctx->n, DENS_RHO_EOS, ctx->variant);
     if (ev) (void)hipEventRecord(ev[SPH_K_FORCE_KICK], st);
     launch_force(st, ctx->c, ctx->a, ctx->n, true, ctx->variant);
     if (ev) (void)hipEventRecord(ev[SPH_K_HALO], st);   // = end of step
@@ -250,7 +251,7 @@ int sph_create(sph_ctx **out, const sph_params *prm, const sph_particle *fluid, 
     const size_t tiles = pad / SCAN_TILE;
 #define ALLOC(ptr, cnt) if ((rc = dalloc(ctx, &(ptr), (cnt))) != SPH_OK) return rc
     ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
-    ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.slot, n > nb ? n : nb);
+    ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.hitmask, 3 * n); ALLOC(a.skey, n); ALLOC(a.tiles, 10 * ((n + 255) / 256 + 1)); ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
     ALLOC(a.bpos, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT);
@@ -278,7 +279,7 @@ int sph_create(sph_ctx **out, const sph_params *prm, const sph_particle *fluid, 
     launch_upload_state(st, a, n_fluid, ctx->d_aos);
     if ((rc = resort_state(ctx)) != SPH_OK) return rc;
     launch_set_gravity(st, a, gx, gy);
-    launch_density(st, ctx->c, a, n_fluid, true, ctx->variant);
+    launch_density(st, ctx->c, a, n_fluid, DENS_RHO_EOS, ctx->variant);
     launch_force(st, ctx->c, a, n_fluid, false, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(st));   // also keeps hb / fluid alive until the copies are done
@@ -371,6 +372,7 @@ int sph_set_variant(sph_ctx *ctx, int variant) {
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         drop_graph(ctx);
         ctx->variant = variant;
+        if (ctx->stream) launch_density(ctx->stream, ctx->c, ctx->a, ctx->n, DENS_MASKS_ONLY, ctx->variant);
     }
     return SPH_OK;
 }
@@ -401,6 +403,7 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     int rc = resort_state(ctx);
     if (rc) return rc;
     launch_gather_rho_p(st, ctx->c, ctx->a, ctx->n, ctx->d_aos);
+    launch_density(st, ctx->c, ctx->a, ctx->n, DENS_MASKS_ONLY, ctx->variant);   // neighbour masks of the new order
     HIPCHK(ctx, hipGetLastError());
     return check_flags(ctx);
 }
@@ -408,7 +411,7 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
 int sph_eval_density(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
-    launch_density(ctx->stream, ctx->c, ctx->a, ctx->n, false, ctx->variant);
+    launch_density(ctx->stream, ctx->c, ctx->a, ctx->n, DENS_RHO, ctx->variant);
     launch_eos(ctx->stream, ctx->c, ctx->a, ctx->n, true);   // keep p/rho^2 consistent with the new rho and the stored p
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
@@ -453,6 +456,24 @@ int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_t
     for (int k = 0; k < SPH_K_HALO; k++) out->ms[k] = (float)(acc[k] / nsteps);
     out->step_ms = (float)(total / nsteps);
     out->nsteps = nsteps;
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
+    if (!ctx || !ctx->stream || !ms || reps <= 0) return SPH_E_ARG;
+    if (kernel != SPH_K_DENSITY_EOS && kernel != SPH_K_FORCE_KICK) return fail(ctx, SPH_E_ARG, "sph_time_kernel: kernel is not idempotent");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    for (int r = 0; r < reps; r++) {
+        if (kernel == SPH_K_DENSITY_EOS) launch_density(ctx->stream, ctx->c, ctx->a, ctx->n, DENS_RHO_EOS, ctx->variant);
+        else launch_force(ctx->stream, ctx->c, ctx->a, ctx->n, true, ctx->variant);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
+    float t = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
+    *ms = t / reps;
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }

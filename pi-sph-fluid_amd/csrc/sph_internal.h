@@ -32,6 +32,7 @@ struct Consts {
     // range of the sorted arrays (3 contiguous candidate ranges per particle; slab halos are
     // contiguous).  The reference is row-major (:113); the pair sets are identical.
     float x_min, y_min, cell; // cell length 2H :596
+    float inv_cell;           // 1/cell: the device bins with a multiply (see cell_of)
     int rows, cols;          // n_cells (y), m_cells (x) :93-94
     int n_cells;             // rows * cols
 };
@@ -45,6 +46,9 @@ struct Arrays {
     float2 *rp;        // rho, p/rho^2
     float *prs;        // p
     float2 *acc;       // du_dt, dv_dt
+    uint32_t *skey;    // sorted cell keys
+    uint32_t *tiles;   // one 40-byte TileInfo record per 256-particle workgroup (sph_tiled.inc)
+    uint32_t *hitmask; // 3 x n: per particle, per candidate segment, bit k = candidate k is a neighbour (density -> force)
     // staging (T)
     float4 *pk;        // x, y, id bits, cell key bits (after kick/drift, before the sort)
     float2 *velt;      // u,v : the integrated velocity lives here between steps
@@ -79,7 +83,11 @@ void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *cel
                  hipEvent_t mid /* optional: recorded between the two scan kernels */);
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int n);
 // variant: 0 = LDS-tiled (default), 1 = direct global loads
-void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int n, bool with_eos, int variant);
+// mode: what the density pass writes.  The tiled force kernel consumes the neighbour masks the tiled
+// density kernel wrote for the SAME sorted order, so every re-sort must be followed by a density launch
+// (any mode) before a force launch.
+enum { DENS_RHO = 0, DENS_RHO_EOS = 1, DENS_MASKS_ONLY = 2 };
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int n, int mode, int variant);
 void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int n, bool from_prs);
 void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int n, bool kick, int variant);
 // boundary init: bin + pseudo-mass (:600-601, :242-261)

@@ -12,6 +12,8 @@
 // (cell = col*rows + row), so the 3x3 neighbourhood of a particle is THREE contiguous ranges
 // of the sorted arrays (one per column: rows r-1..r+1).  No MFMA anywhere: there is no dense
 // contraction in this workload; the kernels are HBM/LDS/VALU work.
+#include <cstdlib>
+
 #include "sph_internal.h"
 
 namespace sph {
@@ -22,11 +24,15 @@ constexpr int BLK = 256;   // 4 waves of 64
 
 DEV bool finite_bits(float x) { return (__float_as_uint(x) & 0x7fffffffu) < 0x7f800000u; }
 
-// cell of a position, clamped into the grid. Same arithmetic as :111-112 (true division,
-// truncation toward zero); out-of-range and NaN are reported through `oob` / `bad`.
+// cell of a position, clamped into the grid; out-of-range and NaN are reported through `oob` / `bad`.
+// The reference bins with (int)((y - y_min) / cell_length) (:111-112).  The device multiplies by 1/cell instead:
+// an IEEE f32 division costs ~20 instructions plus two FP-mode switches per call here (it was 37 us of the force
+// kernel at 2M particles).  A position within 1 ulp of a cell edge may land in the adjacent cell; that cannot lose
+// a neighbour that matters: a pair missed that way is at distance > 2H(1 - 1e-7), where W and grad W vanish like
+// (1 - q/2)^4 and (1 - q/2)^3.  Every kernel uses this one function, so keys, tiles and ranges agree.
 DEV void cell_of(const Consts &c, float x, float y, int &row, int &col, bool &oob, bool &bad) {
     bad = !(finite_bits(x) && finite_bits(y));
-    float fr = (y - c.y_min) / c.cell, fc = (x - c.x_min) / c.cell;
+    float fr = (y - c.y_min) * c.inv_cell, fc = (x - c.x_min) * c.inv_cell;
     row = bad ? 0 : (int)fr;
     col = bad ? 0 : (int)fc;
     oob = (fr < 0.0f) | (fc < 0.0f) | (row >= c.rows) | (col >= c.cols);
@@ -60,26 +66,49 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
                                                         float2 *__restrict__ velt, float4 *__restrict__ pk,
                                                         uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
                                                         uint32_t *__restrict__ flags, int n) {
-    int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= n) return;
-    float2 p = pos[i];
-    if (INTEGRATE) {
-        float2 v = velt[i];
-        float2 a = acc[i];
-        v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
-        v.y = fmaf(c.half_dt, a.y, v.y);
-        p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
-        p.y = fmaf(c.dt, v.y, p.y);
-        velt[i] = v;
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool active = i < n;
+    uint32_t key = 0xffffffffu;
+    float2 p = make_float2(0.0f, 0.0f);
+    bool oob = false, bad = false;
+    if (active) {
+        p = pos[i];
+        if (INTEGRATE) {
+            float2 v = velt[i];
+            float2 a = acc[i];
+            v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
+            v.y = fmaf(c.half_dt, a.y, v.y);
+            p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
+            p.y = fmaf(c.dt, v.y, p.y);
+            velt[i] = v;
+        }
+        int row, col;
+        cell_of(c, p.x, p.y, row, col, oob, bad);
+        key = (uint32_t)(col * c.rows + row);
     }
-    int row, col;
-    bool oob, bad;
-    cell_of(c, p.x, p.y, row, col, oob, bad);
-    uint32_t key = (uint32_t)(col * c.rows + row);
-    pk[i] = make_float4(p.x, p.y, __uint_as_float(id[i]), __uint_as_float(key));
-    slot[i] = atomicAdd(&count[key], 1u);
-    if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
-    else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
+    // The array is in last step's cell order and a particle moves << one cell per step, so
+    // neighbouring lanes mostly share their new cell.  One histogram atomic per run of equal
+    // keys (run head adds the run length, members take consecutive slots) instead of one per
+    // particle: ~7x fewer atomics and no same-address serialisation inside the wave.
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool head = active && (lane == 0 || prev != key);
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long am = __ballot(active);
+    if (active) {
+        const unsigned long long below = hm & ((2ull << lane) - 1ull);       // run heads at or below this lane
+        const int start = 63 - __builtin_clzll(below);
+        const unsigned long long above = (start == 63) ? 0ull : (hm >> (start + 1));
+        int next = above ? start + __builtin_ffsll((long long)above) : 64;
+        next = min(next, 64 - __builtin_clzll(am));                          // active lanes are a prefix of the wave
+        uint32_t base = 0;
+        if (lane == start) base = atomicAdd(&count[key], (uint32_t)(next - start));
+        base = __shfl(base, start, 64);
+        slot[i] = base + (uint32_t)(lane - start);
+        pk[i] = make_float4(p.x, p.y, __uint_as_float(id[i]), __uint_as_float(key));
+        if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
+        else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
+    }
 }
 
 void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int n) {
@@ -182,21 +211,26 @@ void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *cel
 __global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, const float2 *__restrict__ velt,
                                                  const uint32_t *__restrict__ slot,
                                                  const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
-                                                 float2 *__restrict__ vel, uint32_t *__restrict__ id, int n) {
+                                                 float2 *__restrict__ vel, uint32_t *__restrict__ id,
+                                                 uint32_t *__restrict__ skey, int n) {
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
     float4 q = pk[i];
-    uint32_t dst = cell_start[__float_as_uint(q.w)] + slot[i];
+    const uint32_t key = __float_as_uint(q.w);
+    uint32_t dst = cell_start[key] + slot[i];
     pos[dst] = make_float2(q.x, q.y);
     vel[dst] = velt[i];
     id[dst] = __float_as_uint(q.z);
+    skey[dst] = key;        // sorted keys: the tile table of the tiled kernels is built from them
 }
 
+void launch_tile_table(hipStream_t st, const Consts &c, const Arrays &a, int n);   // sph_tiled.inc
+
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int n) {
-    (void)c;
     if (n <= 0) return;
     hipLaunchKernelGGL(k_reorder, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, a.pk, a.velt, a.slot, a.cell_start, a.pos,
-                       a.vel, a.id, n);
+                       a.vel, a.id, a.skey, n);
+    launch_tile_table(st, c, a, n);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -355,11 +389,12 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
 
 namespace sph {
 
-void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int n, bool with_eos, int variant) {
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int n, int mode, int variant) {
     if (n <= 0) return;
-    if (variant == 0) { launch_density_tiled(st, c, a, n, with_eos); return; }
+    if (variant == 0) { launch_density_tiled(st, c, a, n, mode); return; }
+    if (mode == DENS_MASKS_ONLY) return;      // the direct variant has no masks
     dim3 g((n + BLK - 1) / BLK), b(BLK);
-    if (with_eos)
+    if (mode == DENS_RHO_EOS)
         hipLaunchKernelGGL(k_density_direct<true>, g, b, 0, st, c, a.pos, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
                            a.rp, a.prs, n);
     else

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""profiles/summarize.py <gpurun_out/prof_TAG> [out.md] — condense the rocprofv3 CSVs written by
+profiles/collect.sh into one markdown summary (per-kernel time from --kernel-trace --stats, PMC
+counters averaged per dispatch, HBM traffic corrected as MI355X_MICROARCH.md §HBM prescribes:
+FETCH_SIZE x2 for wide coalesced reads on gfx950, WRITE_SIZE as is; both are reported in KiB)."""
+import csv
+import collections
+import os
+import sys
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("sph::", "")
+    return n
+
+
+def kernel_stats(path):
+    rows = []
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((short(r["Name"]), int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]),
+                         float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+    return rows
+
+
+def pmc(path):
+    """mean counter value per dispatch for each (kernel, counter)."""
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            k = (short(r["Kernel_Name"]), r["Counter_Name"])
+            acc[k][0] += float(r["Counter_Value"])
+            acc[k][1] += 1
+    out = collections.defaultdict(dict)
+    for (kn, cn), (s, n) in acc.items():
+        out[kn][cn] = s / n
+    return out
+
+
+def main():
+    d = sys.argv[1]
+    lines = ["# rocprofv3 summary: %s" % os.path.basename(d.rstrip("/")), ""]
+    ks = os.path.join(d, "trace", "trace_kernel_stats.csv")
+    if os.path.exists(ks):
+        lines += ["## per-kernel time (`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-also --steps 300 --warmup 100`)", "",
+                  "| kernel | calls | avg us | % | min us | max us |", "|---|---|---|---|---|---|"]
+        for n, c, a, p, mn, mx in kernel_stats(ks):
+            lines.append("| %s | %d | %.2f | %.2f | %.2f | %.2f |" % (n, c, a, p, mn, mx))
+        lines.append("")
+    merged = collections.defaultdict(dict)
+    for sub in sorted(os.listdir(d)):
+        f = os.path.join(d, sub, "pmc_counter_collection.csv")
+        if os.path.exists(f):
+            for kn, cs in pmc(f).items():
+                merged[kn].update(cs)
+    if merged:
+        counters = sorted({c for cs in merged.values() for c in cs})
+        lines += ["## PMC counters, mean per dispatch (separate `--pmc` passes, 10 steps after 30 warm-up)", "",
+                  "| kernel | " + " | ".join(counters) + " |", "|---|" + "---|" * len(counters)]
+        for kn in sorted(merged):
+            lines.append("| %s | " % kn + " | ".join("%.4g" % merged[kn][c] if c in merged[kn] else "" for c in counters) + " |")
+        lines.append("")
+        lines += ["## HBM traffic per launch (FETCH_SIZE, WRITE_SIZE in KiB; gfx950: wide coalesced reads are tallied at 1/2,",
+                  "so the read side is doubled as MI355X_MICROARCH.md §HBM prescribes — an upper bound where reads are narrow)", "",
+                  "| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | read MB (x2) | write MB | total MB |", "|---|---|---|---|---|---|"]
+        for kn in sorted(merged):
+            cs = merged[kn]
+            if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
+                fs, ws = cs.get("FETCH_SIZE", 0.0), cs.get("WRITE_SIZE", 0.0)
+                rd, wr = 2 * fs * 1024 / 1e6, ws * 1024 / 1e6
+                lines.append("| %s | %.0f | %.0f | %.2f | %.2f | %.2f |" % (kn, fs, ws, rd, wr, rd + wr))
+        lines.append("")
+    text = "\n".join(lines)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(text + "\n")
+    print(text)
+
+
+if __name__ == "__main__":
+    main()

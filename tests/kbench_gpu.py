@@ -1,0 +1,23 @@
+"""Manual kernel timing (not collected by pytest): cfg2 after warm-up, back-to-back launches of the two heavy
+kernels, then the force-kernel ablation builds (SPH_ABLATE: 1 = no hit loops, 2 = no staging, 3 = neither).
+Usage: python tests/kbench_gpu.py [warmup_steps]"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sph = importlib.import_module("pi-sph-fluid_amd")
+warm = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+prm, f, b = sph.dam_break(1)
+os.environ.pop("SPH_ABLATE", None)
+ctx = sph.Context(prm, f, b)
+ctx.step(warm)
+ctx.sync()
+print("density %.2f us" % (ctx.time_kernel("density_eos", 50) * 1e3))
+for abl in ("0", "1", "2", "3", "7", "15", "0"):
+    os.environ["SPH_ABLATE"] = abl
+    print("force SPH_ABLATE=%s : %.2f us" % (abl, ctx.time_kernel("force_kick", 50) * 1e3))
+os.environ.pop("SPH_ABLATE", None)
+ctx.step(1)
+ctx.sync()

@@ -4,19 +4,31 @@
   G1 density        from identical f32 (x,y):                max |drho|/rho <= 1e-5
   G2 pressure       from identical f32 rho (uploaded):       |dp| <= 1e-5 (p + B)
   G3 acceleration   from identical f32 (x,y,u,v,rho,p):      |da| <= 1e-5 (sum_j |m_j temp_ij gradW_ij| + |g|)
-  G4 end-to-end     rho -> p -> a all recomputed:            rms|da|/rms|a| <= 2e-3, max|da| <= 1 m/s^2 (loose by
-                    construction: B = 2.3e7 amplifies 1-ulp density noise; the reference misses tighter bounds
-                    against itself, tests/golden/manifest.json "fast_vs_strict")
+  G4 end-to-end     rho -> p -> a all recomputed: loose by construction (B = 2.3e7 turns 1 ulp of rho into
+                    ~10 Pa).  Calibrated per fixture against the reference's OWN self-consistency, i.e. its
+                    as-shipped -Ofast build vs its -O2 build on the same state (tests/golden/manifest.json
+                    "fast_vs_strict"): rms|da|/rms|a| <= max(2e-3, 2 x self), max|da| <= max(1 m/s^2, 4 x self)
   G5 trajectory     default scene: max|dx| <= 1e-5 m at step 100, <= 1e-3 m at step 1000
   G7 invariants     pair antisymmetry, rest state, determinism of read-back order
 
 Expected values come from the golden fixtures (real reference) and, for inputs beyond the
 reference's 65 534-particle limit, from the CPU oracle that is itself pinned bit-exactly to them.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
-from conftest import B_EOS, GX, GY, boundary_particles, load_golden, particles
+from conftest import B_EOS, GOLDEN, GX, GY, boundary_particles, load_golden, particles
+
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+def self_consistency(name, suffix):
+    """the reference's -Ofast build vs its -O2 build on this fixture (oracle/gen_golden.py)."""
+    fv = MANIFEST["fixtures"][name]["fast_vs_strict"]
+    return fv["k" + suffix[1:]] if suffix else fv
 
 pytestmark = pytest.mark.gpu
 
@@ -70,9 +82,9 @@ def test_staged_gates_on_golden(sph, orc, oracle, name, suffix, variant):
         edu, edv = g["eval_du" + suffix], g["eval_dv" + suffix]
         da = np.hypot(du - edu, dv - edv)
         rms_a = np.sqrt(np.mean(edu.astype(np.float64) ** 2 + edv.astype(np.float64) ** 2))
-        assert np.sqrt(np.mean(da.astype(np.float64) ** 2)) / rms_a <= 2e-3
-        if name != "gas.npz":     # the random gas has rho up to 3x rho0: p ~ 1e10, absolute bound meaningless
-            assert da.max() <= 1.0
+        ref_self = self_consistency(name, suffix)
+        assert np.sqrt(np.mean(da.astype(np.float64) ** 2)) / rms_a <= max(2e-3, 2 * ref_self["a_rms_rel"])
+        assert da.max() <= max(1.0, 4 * ref_self["a_abs"])
         # G2: pressure from the reference's rho
         fin = particles(orc, state, m_fluid(prm), rho=rho_ref, p=np.zeros_like(p_ref))
         ctx.upload_state(fin)
@@ -223,7 +235,7 @@ def test_g7_rest_lattice_far_from_walls(sph):
         a = np.hypot(du, dv)[inner]
         # pair terms are O(m k1 (W/W02)^4 |gradW|) ~ 1e2 m/s^2 each; their lattice sum cancels to rounding
         assert a.max() < 5e-3
-        assert np.ptp(got["rho"][inner]) < 1e-2
+        assert np.ptp(got["rho"][inner]) < 1e-4 * 973.0      # f32 lattice coordinates jitter by ~1 ulp
 
 
 def test_variants_agree(sph):
