@@ -136,7 +136,7 @@ def main():
         sph.build()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("SPH_FORCE_SLAB") == "1":
         from bench_slab import run_slabs          # one process per GPU over RCCL (torch.distributed)
         run_slabs(sph, args)
         return

@@ -145,6 +145,41 @@ size_t sph_device_bytes(const sph_ctx *ctx);
 /* select kernel variant for density/force: 0 = default (best), others for A/B measurements */
 int  sph_set_variant(sph_ctx *ctx, int variant);
 
+/* ---- multi-GPU: x-slab domain decomposition, one process per GPU ----
+ * The reference has no distributed path; this is the sharding of its particle loops (:272, :311) by cell column.
+ * A slab owns the cell columns [col_begin, col_end) of the global grid (:94) and keeps 2 ghost columns per side.
+ * One exchange per step: after kick+drift each slab hands each neighbour the particles now inside that
+ * neighbour's reach (its own 2 outermost columns + anything that just migrated across), as fixed-capacity
+ * buffers: uint32 header[4] = {count,0,0,0} followed by records of 5 words {x, y, u, v, id}.  The host moves the
+ * buffers (RCCL send/recv over xGMI through torch.distributed, or any other transport) between
+ *     sph_slab_step_begin()   kick 1/2 + drift + halo pack                (:615-624)
+ *     sph_slab_step_end()     ingest + sort + density + EOS + force + kick (:626-640)
+ * Ownership follows position: after the sort a slab owns whatever lies in its columns. */
+typedef struct sph_slab_desc {
+    int col_begin, col_end;      /* owned global cell columns [begin, end), at least 4 */
+    int has_left, has_right;     /* a neighbouring slab exists */
+    int halo_capacity;           /* records per halo buffer (0 = default 64 x rows) */
+    int particle_capacity;       /* local particle capacity incl. ghosts (0 = default) */
+} sph_slab_desc;
+
+/* fluid[0..n_fluid) = every particle inside columns [col_begin-2, col_end+2) with its global id;
+ * boundary_all = ALL wall particles of the scene (psi needs the full wall set; the slab keeps its part). */
+int  sph_create_slab(sph_ctx **out, const sph_params *prm, const sph_slab_desc *desc,
+                     const sph_particle *fluid, const uint32_t *ids, int n_fluid,
+                     const sph_particle *boundary_all, int n_boundary_all, float gx, float gy, int device);
+int  sph_slab_step_begin(sph_ctx *ctx, float gx, float gy);
+int  sph_slab_step_end(sph_ctx *ctx);
+/* device addresses and byte size of the four halo buffers (library-owned unless replaced below) */
+int  sph_slab_buffers(sph_ctx *ctx, void **send_left, void **send_right, void **recv_left, void **recv_right, size_t *bytes);
+/* adopt device buffers of the host framework (e.g. torch tensors handed to RCCL); each >= the size above */
+int  sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void *recv_left, void *recv_right, size_t bytes);
+/* host-staged transport (tests, non-RCCL hosts): side 0 = left, 1 = right */
+int  sph_slab_copy_out(sph_ctx *ctx, int side, void *host_bytes);
+int  sph_slab_copy_in(sph_ctx *ctx, int side, const void *host_bytes);
+/* owned particles (any order) with their global ids and accelerations; *n_out = owned count */
+int  sph_slab_read(sph_ctx *ctx, sph_particle *out, uint32_t *ids, float *du_dt, float *dv_dt, int cap, int *n_out);
+int  sph_slab_counts(sph_ctx *ctx, int *n_local, int *n_owned);
+
 /* ---- metaball renderer (next row f1): draw_metaballs :380-411 + pixel grid :570-577 ----
  * 128 x 64 1-bpp SSD1306 page-format bitmap, 1024 bytes: bit (i%8) of byte (i/8)*128+j. */
 int  sph_render_metaballs(sph_ctx *ctx, unsigned char *draw_buffer_1024);

@@ -40,6 +40,8 @@ ABI_SYMBOLS = [
     "sph_upload_state", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
     "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
     "sph_render_metaballs",
+    "sph_create_slab", "sph_slab_step_begin", "sph_slab_step_end", "sph_slab_buffers", "sph_slab_set_buffers",
+    "sph_slab_copy_out", "sph_slab_copy_in", "sph_slab_read", "sph_slab_counts",
 ]
 HOST_SYMBOLS = [
     "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",
@@ -57,6 +59,12 @@ class Params(C.Structure):
 
 class KernelTimes(C.Structure):
     _fields_ = [("ms", C.c_float * 7), ("step_ms", C.c_float), ("nsteps", C.c_int)]
+
+
+class SlabDesc(C.Structure):
+    """sph_slab_desc of include/sph.h."""
+    _fields_ = [("col_begin", C.c_int), ("col_end", C.c_int), ("has_left", C.c_int), ("has_right", C.c_int),
+                ("halo_capacity", C.c_int), ("particle_capacity", C.c_int)]
 
 
 class Gravity(C.Structure):
@@ -124,6 +132,15 @@ def hip_lib():
         L.sph_device_bytes.restype = C.c_size_t
         L.sph_set_variant.argtypes = [vp, ci]
         L.sph_render_metaballs.argtypes = [vp, vp]
+        L.sph_create_slab.argtypes = [C.POINTER(vp), C.POINTER(Params), C.POINTER(SlabDesc), vp, vp, ci, vp, ci, cf, cf, ci]
+        L.sph_slab_step_begin.argtypes = [vp, cf, cf]
+        L.sph_slab_step_end.argtypes = [vp]
+        L.sph_slab_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.sph_slab_set_buffers.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
+        L.sph_slab_copy_out.argtypes = [vp, ci, vp]
+        L.sph_slab_copy_in.argtypes = [vp, ci, vp]
+        L.sph_slab_read.argtypes = [vp, vp, vp, vp, vp, ci, C.POINTER(ci)]
+        L.sph_slab_counts.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
         _hip = L
     return _hip
 
@@ -338,3 +355,6 @@ class Context:
         buf = np.zeros(1024, np.uint8)
         self._chk(self.L.sph_render_metaballs(self.h, buf.ctypes.data_as(C.c_void_p)))
         return buf
+
+
+from . import slab  # noqa: E402,F401  (host-side slab decomposition: partitioner, transports, runner)

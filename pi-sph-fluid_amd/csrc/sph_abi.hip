@@ -24,7 +24,13 @@ struct sph_ctx {
     sph_params prm{};
     Consts c{};
     Arrays a{};
-    int n = 0, nb = 0;
+    int n = 0, nb = 0;          // single mode: fluid / boundary counts; slab mode: n = particles passed at creation
+    int cap = 0;                // capacity of the particle arrays (== n in single mode)
+    bool slab = false;
+    bool slab_mid_step = false; // between sph_slab_step_begin and sph_slab_step_end
+    bool own_halo = false;      // halo buffers allocated by the library (else adopted from the host framework)
+    size_t halo_bytes = 0;
+    uint32_t *d_ids = nullptr;  // slab read-back staging
     int variant = 0;
     sph_particle *d_aos = nullptr;    // n  : read-back / upload staging, original order
     sph_particle *d_baos = nullptr;   // nb
@@ -104,6 +110,11 @@ int make_consts(const sph_params &p, Consts &c) {
     c.rows = (int)rows;
     c.cols = (int)cols;
     c.n_cells = c.rows * c.cols;
+    c.col_off = 0;
+    c.ghost = 0;
+    c.owned = c.cols;
+    c.has_left = c.has_right = 0;
+    c.halo_cap = 0;
     return SPH_OK;
 }
 
@@ -116,15 +127,15 @@ size_t padded_items(const Consts &c) {
 void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (ev) (void)hipEventRecord(ev[SPH_K_KICK_DRIFT_KEY], st);
-    launch_kick_drift_key(st, ctx->c, ctx->a, ctx->n);
+    launch_kick_drift_key(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_SCAN_REDUCE], st);
     launch_scan(st, ctx->c, ctx->a.count, ctx->a.cell_start, ctx->a.block_sums, ev ? ev[SPH_K_SCAN_APPLY] : nullptr);
     if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
-    launch_reorder(st, ctx->c, ctx->a, ctx->n);
+    launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
-    launch_density(st, ctx->c, ctx->a, ctx->n, DENS_RHO_EOS, ctx->variant);
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
     if (ev) (void)hipEventRecord(ev[SPH_K_FORCE_KICK], st);
-    launch_force(st, ctx->c, ctx->a, ctx->n, true, ctx->variant);
+    launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
     if (ev) (void)hipEventRecord(ev[SPH_K_HALO], st);   // = end of step
 }
 
@@ -157,23 +168,26 @@ bool ensure_graph(sph_ctx *ctx) {
 // bin the current (pos, velt, id) state: keys + histogram, scan, scatter; then velt := sorted vel
 int resort_state(sph_ctx *ctx) {
     hipStream_t st = ctx->stream;
-    launch_key_only(st, ctx->c, ctx->a, ctx->n);
+    launch_key_only(st, ctx->c, ctx->a, ctx->cap);
     launch_scan(st, ctx->c, ctx->a.count, ctx->a.cell_start, ctx->a.block_sums, nullptr);
-    launch_reorder(st, ctx->c, ctx->a, ctx->n);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->a.velt, ctx->a.vel, sizeof(float2) * (size_t)ctx->n, hipMemcpyDeviceToDevice, st));
+    launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->a.velt, ctx->a.vel, sizeof(float2) * (size_t)ctx->cap, hipMemcpyDeviceToDevice, st));
     return SPH_OK;
 }
 
 int check_flags(sph_ctx *ctx) {
-    uint32_t h[2] = {0, 0};
+    uint32_t h[FLAG_COUNT] = {0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h[0] | h[1]) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->a.flags, 0, sizeof h, ctx->stream));
+    if (h[FLAG_OOB] | h[FLAG_NAN] | h[FLAG_CAPACITY]) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->a.flags, 0, 2 * sizeof(uint32_t), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_CAPACITY, 0, sizeof(uint32_t), ctx->stream));
         ctx->oob_total += h[FLAG_OOB];
         ctx->nan_total += h[FLAG_NAN];
         if (h[FLAG_NAN]) return fail(ctx, SPH_E_NAN, "particle positions became NaN/Inf");
-        return fail(ctx, SPH_E_OUT_OF_DOMAIN, "particles left the domain and were clamped into edge cells");
+        if (h[FLAG_CAPACITY]) return fail(ctx, SPH_E_CAPACITY, "slab particle or halo capacity exceeded");
+        return fail(ctx, SPH_E_OUT_OF_DOMAIN, ctx->slab ? "particles left the slab's local grid and were clamped into edge cells"
+                                                        : "particles left the domain and were clamped into edge cells");
     }
     return SPH_OK;
 }
@@ -222,23 +236,46 @@ void sph_destroy(sph_ctx *ctx) {
     delete ctx;
 }
 
-int sph_create(sph_ctx **out, const sph_params *prm, const sph_particle *fluid, int n_fluid,
-               const sph_particle *boundary, int n_boundary, float gx, float gy, int device) {
-    if (!out) return SPH_E_ARG;
-    *out = nullptr;
-    sph_ctx *ctx = new sph_ctx();
-    *out = ctx;   // returned even on failure so that sph_last_error() can be read; caller destroys it
-    if (!prm || n_fluid < 0 || n_boundary < 0 || (n_fluid > 0 && !fluid) || (n_boundary > 0 && !boundary))
-        return fail(ctx, SPH_E_ARG, "sph_create: null pointer or negative count");
+}  // extern "C"
+
+namespace {
+
+struct SlabSpec {          // internal form of sph_slab_desc
+    int col_begin, col_end, has_left, has_right, halo_cap, particle_cap;
+};
+
+// Shared by sph_create and sph_create_slab: allocate, bin the boundary (psi given or computed), upload the fluid,
+// bin it, evaluate rho, p, a at t = 0 (:594-607).  ids == nullptr: ids are 0..n-1.
+int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid, const uint32_t *ids, int n_fluid,
+                 const sph_particle *boundary, int n_boundary, bool psi_given, float gx, float gy, int device,
+                 const SlabSpec *slab) {
     ctx->prm = *prm;
-    if (make_consts(*prm, ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "sph_create: invalid parameters or grid too large");
+    if (make_consts(*prm, ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "invalid parameters or grid too large");
+    if (slab) {
+        Consts &c = ctx->c;
+        const int G = 2;
+        if (slab->col_begin < 0 || slab->col_end > c.cols || slab->col_end - slab->col_begin < 4)
+            return fail(ctx, SPH_E_ARG, "slab must own at least 4 cell columns inside the grid");
+        c.col_off = slab->col_begin - G;
+        c.ghost = G;
+        c.owned = slab->col_end - slab->col_begin;
+        c.cols = c.owned + 2 * G;
+        if ((double)c.rows * c.cols > 1.0e9) return fail(ctx, SPH_E_ARG, "local grid too large");
+        c.n_cells = c.rows * c.cols;
+        c.has_left = slab->has_left;
+        c.has_right = slab->has_right;
+        c.halo_cap = slab->halo_cap;
+        ctx->slab = true;
+    }
     for (int i = 0; i < n_fluid; i++)
         if (std::fabs(fluid[i].m - ctx->c.m_fluid) > 1e-6f * ctx->c.m_fluid)
-            return fail(ctx, SPH_E_ARG, "sph_create: fluid mass must be uniform and equal rho0*vol (pi_sph_fluid.c:502)");
+            return fail(ctx, SPH_E_ARG, "fluid mass must be uniform and equal rho0*vol (pi_sph_fluid.c:502)");
     int rc = select_device(ctx, device);
     if (rc) return rc;
     ctx->n = n_fluid;
     ctx->nb = n_boundary;
+    ctx->cap = slab ? slab->particle_cap : n_fluid;
+    if (ctx->cap < n_fluid) return fail(ctx, SPH_E_ARG, "particle capacity smaller than the initial particle count");
     if (const char *e = getenv("SPH_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
     if (const char *e = getenv("SPH_VARIANT")) ctx->variant = atoi(e);
 
@@ -247,49 +284,131 @@ int sph_create(sph_ctx **out, const sph_params *prm, const sph_particle *fluid, 
     for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
 
     Arrays &a = ctx->a;
-    const size_t n = (size_t)n_fluid, nb = (size_t)n_boundary, pad = padded_items(ctx->c);
+    const size_t n = (size_t)ctx->cap, nb = (size_t)n_boundary, pad = padded_items(ctx->c);
     const size_t tiles = pad / SCAN_TILE;
 #define ALLOC(ptr, cnt) if ((rc = dalloc(ctx, &(ptr), (cnt))) != SPH_OK) return rc
     ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
-    ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.hitmask, 3 * n); ALLOC(a.skey, n); ALLOC(a.tiles, 10 * ((n + 255) / 256 + 1)); ALLOC(a.slot, n > nb ? n : nb);
+    ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.hitmask, 3 * n); ALLOC(a.skey, n);
+    ALLOC(a.tiles, 10 * ((n + 255) / 256 + 1)); ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
     ALLOC(a.bpos, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
-    ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT);
+    ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 64 * 128);
+    ALLOC(ctx->d_ids, n);
     float2 *bpos_in = nullptr;
     uint32_t *bkey = nullptr;
     ALLOC(bpos_in, nb); ALLOC(bkey, nb);
+    a.send[0] = a.send[1] = a.recv[0] = a.recv[1] = nullptr;
+    if (slab) {
+        ctx->halo_bytes = sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * slab->halo_cap);
+        for (int k = 0; k < 2; k++) { ALLOC(a.send[k], ctx->halo_bytes / 4); ALLOC(a.recv[k], ctx->halo_bytes / 4); }
+        ctx->own_halo = true;
+    }
 #undef ALLOC
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.acc, 0, (n ? n : 1) * sizeof(float2), st));
+    if (slab)
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(ctx, hipMemsetAsync(a.send[k], 0, ctx->halo_bytes, st));
+            HIPCHK(ctx, hipMemsetAsync(a.recv[k], 0, ctx->halo_bytes, st));
+        }
+    const uint32_t hdn[4] = {(uint32_t)n_fluid, (uint32_t)n_fluid, 0u, 0u};
+    HIPCHK(ctx, hipMemcpyAsync(a.dn, hdn, sizeof hdn, hipMemcpyHostToDevice, st));
 
     // boundary: bin once, pseudo-mass once (:600-601)
     std::vector<float2> hb(nb ? nb : 1);
-    for (size_t i = 0; i < nb; i++) hb[i] = make_float2(boundary[i].x, boundary[i].y);
+    std::vector<float> hpsi(nb ? nb : 1);
+    for (size_t i = 0; i < nb; i++) { hb[i] = make_float2(boundary[i].x, boundary[i].y); hpsi[i] = boundary[i].m; }
     HIPCHK(ctx, hipMemcpyAsync(bpos_in, hb.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
     launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.flags, n_boundary);
     launch_scan(st, ctx->c, a.count, a.bcell_start, a.block_sums, nullptr);
     launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary);
-    launch_boundary_psi(st, ctx->c, a, n_boundary);
+    if (psi_given) {
+        // psi was computed on the full wall set (a slab sees only its part of the walls): scatter it to bin order
+        float *psi_in = reinterpret_cast<float *>(bkey);      // bkey is dead after the reorder
+        HIPCHK(ctx, hipMemcpyAsync(psi_in, hpsi.data(), nb * sizeof(float), hipMemcpyHostToDevice, st));
+        launch_boundary_gather_psi(st, a, psi_in, n_boundary);
+    } else {
+        launch_boundary_psi(st, ctx->c, a, n_boundary);
+    }
 
     // fluid: upload, bin, then rho, p, a at t = 0 (:604-607)
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, n * sizeof(sph_particle), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, (size_t)n_fluid * sizeof(sph_particle), hipMemcpyHostToDevice, st));
     launch_upload_state(st, a, n_fluid, ctx->d_aos);
+    if (ids) HIPCHK(ctx, hipMemcpyAsync(a.id, ids, (size_t)n_fluid * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if ((rc = resort_state(ctx)) != SPH_OK) return rc;
     launch_set_gravity(st, a, gx, gy);
-    launch_density(st, ctx->c, a, n_fluid, DENS_RHO_EOS, ctx->variant);
-    launch_force(st, ctx->c, a, n_fluid, false, ctx->variant);
+    launch_density(st, ctx->c, a, ctx->cap, DENS_RHO_EOS, ctx->variant);
+    launch_force(st, ctx->c, a, ctx->cap, false, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(st));   // also keeps hb / fluid alive until the copies are done
-    rc = check_flags(ctx);
-    return rc;
+    return check_flags(ctx);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sph_create(sph_ctx **out, const sph_params *prm, const sph_particle *fluid, int n_fluid,
+               const sph_particle *boundary, int n_boundary, float gx, float gy, int device) {
+    if (!out) return SPH_E_ARG;
+    *out = nullptr;
+    sph_ctx *ctx = new sph_ctx();
+    *out = ctx;   // returned even on failure so that sph_last_error() can be read; caller destroys it
+    if (!prm || n_fluid < 0 || n_boundary < 0 || (n_fluid > 0 && !fluid) || (n_boundary > 0 && !boundary))
+        return fail(ctx, SPH_E_ARG, "sph_create: null pointer or negative count");
+    return init_context(ctx, prm, fluid, nullptr, n_fluid, boundary, n_boundary, false, gx, gy, device, nullptr);
+}
+
+int sph_create_slab(sph_ctx **out, const sph_params *prm, const sph_slab_desc *desc, const sph_particle *fluid,
+                    const uint32_t *ids, int n_fluid, const sph_particle *boundary_all, int n_boundary_all, float gx,
+                    float gy, int device) {
+    if (!out) return SPH_E_ARG;
+    *out = nullptr;
+    sph_ctx *ctx = new sph_ctx();
+    *out = ctx;
+    if (!prm || !desc || n_fluid < 0 || n_boundary_all < 0 || (n_fluid > 0 && (!fluid || !ids)) ||
+        (n_boundary_all > 0 && !boundary_all))
+        return fail(ctx, SPH_E_ARG, "sph_create_slab: null pointer or negative count");
+    // Akinci psi needs every wall neighbour of a wall particle; a slab holds only its part of the walls, so psi
+    // is evaluated once on the full wall set (a throw-away single-mode context without fluid), then filtered.
+    std::vector<sph_particle> ball(n_boundary_all ? n_boundary_all : 1);
+    {
+        sph_ctx *tmp = nullptr;
+        int rc = sph_create(&tmp, prm, nullptr, 0, boundary_all, n_boundary_all, gx, gy, device);
+        if (rc == SPH_OK) rc = sph_read_boundary(tmp, ball.data());
+        if (rc != SPH_OK) {
+            ctx->err = std::string("sph_create_slab: wall pseudo-mass pass failed: ") + (tmp ? tmp->err : "");
+            sph_destroy(tmp);
+            return rc;
+        }
+        sph_destroy(tmp);
+    }
+    Consts cg;
+    if (make_consts(*prm, cg) != SPH_OK) return fail(ctx, SPH_E_ARG, "sph_create_slab: invalid parameters");
+    const int lo = desc->col_begin - 2, hi = desc->col_end + 2;   // local columns [lo, hi)
+    std::vector<sph_particle> bloc;
+    for (int i = 0; i < n_boundary_all; i++) {
+        const float fc = (ball[i].x - cg.x_min) * cg.inv_cell;     // same arithmetic as the device's cell_of
+        const int col = (int)fc;
+        if (fc >= 0.0f && col >= lo && col < hi) bloc.push_back(ball[i]);
+    }
+    SlabSpec sp;
+    sp.col_begin = desc->col_begin;
+    sp.col_end = desc->col_end;
+    sp.has_left = desc->has_left != 0;
+    sp.has_right = desc->has_right != 0;
+    sp.halo_cap = desc->halo_capacity > 0 ? desc->halo_capacity : 4 * cg.rows * 16;
+    sp.particle_cap = desc->particle_capacity > 0 ? desc->particle_capacity : n_fluid + n_fluid / 4 + 2 * sp.halo_cap + 1024;
+    return init_context(ctx, prm, fluid, ids, n_fluid, bloc.data(), (int)bloc.size(), true, gx, gy, device, &sp);
 }
 
 int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
     if (!ctx || nsteps < 0) return SPH_E_ARG;
     if (!ctx->stream) return fail(ctx, SPH_E_STATE, "context not initialised");
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_step_begin / exchange / sph_slab_step_end");
     (void)hipSetDevice(ctx->device);
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     const bool g = ensure_graph(ctx);
@@ -309,6 +428,7 @@ int sph_sync(sph_ctx *ctx) {
 
 int sph_read_particles(sph_ctx *ctx, sph_particle *out) {
     if (!ctx || !ctx->stream || (!out && ctx->n)) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_read");
     (void)hipSetDevice(ctx->device);
     launch_unsort_particles(ctx->stream, ctx->c, ctx->a, ctx->n, ctx->d_aos);
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_aos, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyDeviceToHost, ctx->stream));
@@ -318,6 +438,7 @@ int sph_read_particles(sph_ctx *ctx, sph_particle *out) {
 
 int sph_read_accel(sph_ctx *ctx, float *du_dt, float *dv_dt) {
     if (!ctx || !ctx->stream || ((!du_dt || !dv_dt) && ctx->n)) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_read");
     (void)hipSetDevice(ctx->device);
     launch_unsort_accel(ctx->stream, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
     HIPCHK(ctx, hipMemcpyAsync(du_dt, ctx->d_du, (size_t)ctx->n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -372,7 +493,7 @@ int sph_set_variant(sph_ctx *ctx, int variant) {
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         drop_graph(ctx);
         ctx->variant = variant;
-        if (ctx->stream) launch_density(ctx->stream, ctx->c, ctx->a, ctx->n, DENS_MASKS_ONLY, ctx->variant);
+        if (ctx->stream) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_MASKS_ONLY, ctx->variant);
     }
     return SPH_OK;
 }
@@ -396,6 +517,7 @@ int sph_set_stream(sph_ctx *ctx, void *hip_stream) {
 // ---- stage entry points ----
 int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     if (!ctx || !ctx->stream || (!fluid && ctx->n)) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "stage entry points are single-GPU only");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyHostToDevice, st));
@@ -403,7 +525,7 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     int rc = resort_state(ctx);
     if (rc) return rc;
     launch_gather_rho_p(st, ctx->c, ctx->a, ctx->n, ctx->d_aos);
-    launch_density(st, ctx->c, ctx->a, ctx->n, DENS_MASKS_ONLY, ctx->variant);   // neighbour masks of the new order
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_MASKS_ONLY, ctx->variant);   // neighbour masks of the new order
     HIPCHK(ctx, hipGetLastError());
     return check_flags(ctx);
 }
@@ -411,8 +533,8 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
 int sph_eval_density(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
-    launch_density(ctx->stream, ctx->c, ctx->a, ctx->n, DENS_RHO, ctx->variant);
-    launch_eos(ctx->stream, ctx->c, ctx->a, ctx->n, true);   // keep p/rho^2 consistent with the new rho and the stored p
+    launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO, ctx->variant);
+    launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, true);   // keep p/rho^2 consistent with the new rho and the stored p
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
@@ -420,7 +542,7 @@ int sph_eval_density(sph_ctx *ctx) {
 int sph_eval_pressure(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
-    launch_eos(ctx->stream, ctx->c, ctx->a, ctx->n, false);
+    launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, false);
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
@@ -429,7 +551,7 @@ int sph_eval_accel(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
-    launch_force(ctx->stream, ctx->c, ctx->a, ctx->n, false, ctx->variant);
+    launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, false, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
@@ -437,6 +559,7 @@ int sph_eval_accel(sph_ctx *ctx, float gx, float gy) {
 // ---- measurement ----
 int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_times *out) {
     if (!ctx || !ctx->stream || !out || nsteps <= 0) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_profile_steps is single-GPU only");
     (void)hipSetDevice(ctx->device);
     memset(out, 0, sizeof *out);
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
@@ -466,8 +589,8 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int r = 0; r < reps; r++) {
-        if (kernel == SPH_K_DENSITY_EOS) launch_density(ctx->stream, ctx->c, ctx->a, ctx->n, DENS_RHO_EOS, ctx->variant);
-        else launch_force(ctx->stream, ctx->c, ctx->a, ctx->n, true, ctx->variant);
+        if (kernel == SPH_K_DENSITY_EOS) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
+        else launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
@@ -478,9 +601,115 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     return SPH_OK;
 }
 
+// ---- slab decomposition ----
+int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (!ctx->slab || ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_step_begin: not a slab context or already mid-step");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    launch_set_gravity(st, ctx->a, gx, gy);
+    for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, HALO_HDR * sizeof(uint32_t), st));
+    launch_kick_drift_key(st, ctx->c, ctx->a, ctx->cap);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->slab_mid_step = true;
+    return SPH_OK;
+}
+
+int sph_slab_step_end(sph_ctx *ctx) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (!ctx->slab || !ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_begin");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    launch_ingest(st, ctx->c, ctx->a, ctx->cap);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.cell_start, ctx->a.block_sums, nullptr);
+    launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
+    launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->slab_mid_step = false;
+    return SPH_OK;
+}
+
+int sph_slab_buffers(sph_ctx *ctx, void **send_left, void **send_right, void **recv_left, void **recv_right, size_t *bytes) {
+    if (!ctx || !ctx->slab) return SPH_E_ARG;
+    if (send_left) *send_left = ctx->a.send[0];
+    if (send_right) *send_right = ctx->a.send[1];
+    if (recv_left) *recv_left = ctx->a.recv[0];
+    if (recv_right) *recv_right = ctx->a.recv[1];
+    if (bytes) *bytes = ctx->halo_bytes;
+    return SPH_OK;
+}
+
+int sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void *recv_left, void *recv_right, size_t bytes) {
+    if (!ctx || !ctx->slab || !send_left || !send_right || !recv_left || !recv_right) return SPH_E_ARG;
+    if (bytes < ctx->halo_bytes) return fail(ctx, SPH_E_ARG, "sph_slab_set_buffers: buffers smaller than the halo capacity");
+    if (ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_set_buffers mid-step");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->a.send[0] = static_cast<uint32_t *>(send_left);
+    ctx->a.send[1] = static_cast<uint32_t *>(send_right);
+    ctx->a.recv[0] = static_cast<uint32_t *>(recv_left);
+    ctx->a.recv[1] = static_cast<uint32_t *>(recv_right);
+    ctx->own_halo = false;
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, ctx->halo_bytes, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->a.recv[k], 0, ctx->halo_bytes, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPH_OK;
+}
+
+int sph_slab_copy_out(sph_ctx *ctx, int side, void *host) {
+    if (!ctx || !ctx->slab || side < 0 || side > 1 || !host) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(host, ctx->a.send[side], ctx->halo_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPH_OK;
+}
+
+int sph_slab_copy_in(sph_ctx *ctx, int side, const void *host) {
+    if (!ctx || !ctx->slab || side < 0 || side > 1 || !host) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->a.recv[side], host, ctx->halo_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPH_OK;
+}
+
+int sph_slab_read(sph_ctx *ctx, sph_particle *out, uint32_t *ids, float *du_dt, float *dv_dt, int cap, int *n_out) {
+    if (!ctx || !ctx->stream || !ctx->slab || !n_out) return SPH_E_ARG;
+    if (ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_read mid-step");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    launch_export_owned(st, ctx->c, ctx->a, ctx->cap, ctx->d_aos, ctx->d_ids, ctx->d_du, ctx->d_dv);
+    uint32_t hdn[4] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(hdn, ctx->a.dn, sizeof hdn, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    const int n = (int)hdn[2];
+    *n_out = n;
+    if (n > cap) return fail(ctx, SPH_E_CAPACITY, "sph_slab_read: output capacity too small");
+    if (out) HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_aos, (size_t)n * sizeof(sph_particle), hipMemcpyDeviceToHost, st));
+    if (ids) HIPCHK(ctx, hipMemcpyAsync(ids, ctx->d_ids, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (du_dt) HIPCHK(ctx, hipMemcpyAsync(du_dt, ctx->d_du, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (dv_dt) HIPCHK(ctx, hipMemcpyAsync(dv_dt, ctx->d_dv, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return SPH_OK;
+}
+
+int sph_slab_counts(sph_ctx *ctx, int *n_local, int *n_owned) {
+    if (!ctx || !ctx->stream || !ctx->slab) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    uint32_t hdn[4] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(hdn, ctx->a.dn, sizeof hdn, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_local) *n_local = (int)hdn[0];
+    if (n_owned) *n_owned = (int)hdn[1];
+    return SPH_OK;
+}
+
 // ---- metaballs (next row f1) ----
 int sph_render_metaballs(sph_ctx *ctx, unsigned char *draw_buffer) {
     if (!ctx || !ctx->stream || !draw_buffer) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_render_metaballs is single-GPU only");
     (void)hipSetDevice(ctx->device);
     unsigned char bits[64 * 128];
     launch_metaballs(ctx->stream, ctx->c, ctx->a, ctx->prm.x_max - ctx->prm.x_min, ctx->prm.y_max - ctx->prm.y_min,

@@ -33,8 +33,14 @@ struct Consts {
     // contiguous).  The reference is row-major (:113); the pair sets are identical.
     float x_min, y_min, cell; // cell length 2H :596
     float inv_cell;           // 1/cell: the device bins with a multiply (see cell_of)
-    int rows, cols;          // n_cells (y), m_cells (x) :93-94
+    int rows, cols;          // n_cells (y), m_cells (x) :93-94 — in slab mode: the LOCAL column count (owned + 2*ghost)
     int n_cells;             // rows * cols
+    // slab decomposition (single GPU: col_off = 0, ghost = 0, owned = cols, no neighbours)
+    int col_off;             // global column of local column 0
+    int ghost;               // ghost columns on each side (2: one exchange per step)
+    int owned;               // owned columns: local columns [ghost, ghost + owned)
+    int has_left, has_right; // a neighbouring slab exists on that side
+    int halo_cap;            // records per halo buffer
 };
 
 // Per-context device arrays. "S" = cell-sorted state, "T" = staging written by kick/drift.
@@ -51,7 +57,8 @@ struct Arrays {
     uint32_t *hitmask; // 3 x n: per particle, per candidate segment, bit k = candidate k is a neighbour (density -> force)
     // staging (T)
     float4 *pk;        // x, y, id bits, cell key bits (after kick/drift, before the sort)
-    float2 *velt;      // u,v : the integrated velocity lives here between steps
+    float2 *velt;      // u,v after the second half kick, sorted order: the velocity between steps
+    float2 *velk;      // u,v after the first half kick, staging order (source of the sort)
     uint32_t *slot;    // arrival rank of the particle inside its cell
     // grid
     uint32_t *count;      // per-cell histogram (zero between sorts)
@@ -64,10 +71,15 @@ struct Arrays {
     uint32_t *bcell_start; // n_cells + 1
     // misc
     float2 *grav;       // gravity vector read by the force kernel
-    uint32_t *flags;    // [0] out-of-domain count, [1] NaN count, [2] max rho bits, [3] max speed bits
+    uint32_t *flags;    // [0] out-of-domain count, [1] NaN count, [2] max rho bits, [3] max speed bits, [4] capacity overflow
+    uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
+    // slab halo buffers: uint32 header[4] = {count,..} + halo_cap records of 5 words (x, y, u, v, id)
+    uint32_t *send[2], *recv[2];   // [0] = left neighbour, [1] = right neighbour
 };
 
-enum { FLAG_OOB = 0, FLAG_NAN = 1, FLAG_MAXRHO = 2, FLAG_MAXSPEED = 3, FLAG_COUNT = 8 };
+enum { FLAG_OOB = 0, FLAG_NAN = 1, FLAG_MAXRHO = 2, FLAG_MAXSPEED = 3, FLAG_CAPACITY = 4, FLAG_COUNT = 8 };
+constexpr int HALO_HDR = 4;     // header words of a halo buffer
+constexpr int HALO_REC = 5;     // words per halo record
 
 constexpr int SCAN_ITEMS = 8;            // items per thread in the scan kernels
 constexpr int SCAN_BLOCK = 256;
@@ -75,27 +87,35 @@ constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;   // 2048 cells per block
 
 // ---- launchers (sph_kernels.hip); all asynchronous on `st` ----
 void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy);
-// first half kick + drift + cell key + histogram (:615-624, :111-113)
-void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int n);
+// In every per-step launcher `cap` is the launch capacity (grid size, array stride); the live particle count is
+// read on the device from a.dn[0], so slab mode (count changes every step) and single mode share the kernels.
+// first half kick + drift + cell key + histogram (:615-624, :111-113); in slab mode also packs the halo buffers
+void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 // keys + histogram only, state taken as is (init and sph_upload_state)
-void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int n);
+void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// slab mode: append the received halo records to the staging arrays, then dn[0] = owned + received
+void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap);
+// slab mode: owned particles (sorted order) -> compact AoS + ids; count left in dn[1]... see sph_abi.hip
+void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int cap, sph_particle *out_dev, uint32_t *ids_dev,
+                         float *du, float *dv);
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *cell_start, uint32_t *block_sums,
                  hipEvent_t mid /* optional: recorded between the two scan kernels */);
-void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int n);
+void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 // variant: 0 = LDS-tiled (default), 1 = direct global loads
 // mode: what the density pass writes.  The tiled force kernel consumes the neighbour masks the tiled
 // density kernel wrote for the SAME sorted order, so every re-sort must be followed by a density launch
 // (any mode) before a force launch.
 enum { DENS_RHO = 0, DENS_RHO_EOS = 1, DENS_MASKS_ONLY = 2 };
-void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int n, int mode, int variant);
-void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int n, bool from_prs);
-void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int n, bool kick, int variant);
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant);
+void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool from_prs);
+void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool kick, int variant);
 // boundary init: bin + pseudo-mass (:600-601, :242-261)
 void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in, uint32_t *key, uint32_t *slot,
                          uint32_t *count, uint32_t *flags, int nb);
 void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
                              const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb);
 void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb);
+void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *psi_in_original_order, int nb);
 // read-back helpers
 void launch_unsort_particles(hipStream_t st, const Consts &c, const Arrays &a, int n, sph_particle *out_dev);
 void launch_unsort_accel(hipStream_t st, const Arrays &a, int n, float *du, float *dv);

@@ -34,8 +34,8 @@ DEV void cell_of(const Consts &c, float x, float y, int &row, int &col, bool &oo
     bad = !(finite_bits(x) && finite_bits(y));
     float fr = (y - c.y_min) * c.inv_cell, fc = (x - c.x_min) * c.inv_cell;
     row = bad ? 0 : (int)fr;
-    col = bad ? 0 : (int)fc;
-    oob = (fr < 0.0f) | (fc < 0.0f) | (row >= c.rows) | (col >= c.cols);
+    col = bad ? 0 : (int)fc - c.col_off;          // local column (slab mode: col_off = first local column)
+    oob = (fr < 0.0f) | (fc < 0.0f) | (col < 0) | (row >= c.rows) | (col >= c.cols);
     row = min(max(row, 0), c.rows - 1);
     col = min(max(col, 0), c.cols - 1);
 }
@@ -60,30 +60,59 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy) {
 
 // ------------------------------------------------------------------------------------------
 // P1: kick 1/2 + drift + key + histogram.  44 B/particle + 4 B slot.
-template <bool INTEGRATE>
+// INTEGRATE: read the OWNED range of the sorted arrays (cell_start of the previous sort; single GPU: everything),
+// integrate, write staging entries 0..n_own-1.  !INTEGRATE: take entries 0..dn[0]-1 as they are (init / upload).
+// SLAB: also append every particle now inside a neighbour's reach (its two outermost owned columns, plus the
+// column it may just have migrated into) to that neighbour's halo buffer: ONE exchange per step carries both the
+// ghosts and the ownership migration.
+DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, uint32_t id, uint32_t *__restrict__ flags) {
+    const uint32_t k = atomicAdd(&buf[0], 1u);
+    if (k < (uint32_t)cap) {
+        uint32_t *r = buf + HALO_HDR + (size_t)k * HALO_REC;
+        r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y);
+        r[2] = __float_as_uint(v.x); r[3] = __float_as_uint(v.y);
+        r[4] = id;
+    } else {
+        atomicAdd(&flags[FLAG_CAPACITY], 1u);
+    }
+}
+
+template <bool INTEGRATE, bool SLAB>
 __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *__restrict__ pos,
                                                         const uint32_t *__restrict__ id, const float2 *__restrict__ acc,
-                                                        float2 *__restrict__ velt, float4 *__restrict__ pk,
+                                                        const float2 *__restrict__ velt, const uint32_t *__restrict__ cs,
+                                                        float2 *__restrict__ velk, float4 *__restrict__ pk,
                                                         uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
-                                                        uint32_t *__restrict__ flags, int n) {
-    const int i = blockIdx.x * BLK + threadIdx.x;
+                                                        uint32_t *__restrict__ flags, uint32_t *__restrict__ dn,
+                                                        uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r) {
+    const int t = blockIdx.x * BLK + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool active = i < n;
-    uint32_t key = 0xffffffffu;
-    float2 p = make_float2(0.0f, 0.0f);
+    int src0 = 0, n;
+    if (INTEGRATE) {
+        src0 = (int)cs[c.ghost * c.rows];
+        n = (int)cs[(c.ghost + c.owned) * c.rows] - src0;
+        if (t == 0) dn[1] = (uint32_t)n;
+    } else {
+        n = (int)dn[0];
+    }
+    const bool active = t < n;
+    uint32_t key = 0xffffffffu, pid = 0u;
+    float2 p = make_float2(0.0f, 0.0f), v = make_float2(0.0f, 0.0f);
     bool oob = false, bad = false;
+    int col = 0;
     if (active) {
+        const int i = src0 + t;
         p = pos[i];
+        v = velt[i];
+        pid = id[i];
         if (INTEGRATE) {
-            float2 v = velt[i];
             float2 a = acc[i];
             v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
             v.y = fmaf(c.half_dt, a.y, v.y);
             p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
             p.y = fmaf(c.dt, v.y, p.y);
-            velt[i] = v;
         }
-        int row, col;
+        int row;
         cell_of(c, p.x, p.y, row, col, oob, bad);
         key = (uint32_t)(col * c.rows + row);
     }
@@ -104,22 +133,68 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
         uint32_t base = 0;
         if (lane == start) base = atomicAdd(&count[key], (uint32_t)(next - start));
         base = __shfl(base, start, 64);
-        slot[i] = base + (uint32_t)(lane - start);
-        pk[i] = make_float4(p.x, p.y, __uint_as_float(id[i]), __uint_as_float(key));
+        slot[t] = base + (uint32_t)(lane - start);
+        pk[t] = make_float4(p.x, p.y, __uint_as_float(pid), __uint_as_float(key));
+        velk[t] = v;
         if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
         else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
+        if (SLAB && INTEGRATE && !bad) {
+            if (c.has_left && col < c.ghost + 2) halo_append(send_l, c.halo_cap, p, v, pid, flags);
+            if (c.has_right && col >= c.ghost + c.owned - 2) halo_append(send_r, c.halo_cap, p, v, pid, flags);
+        }
     }
 }
 
-void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int n) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_kick_drift_key<true>, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.id, a.acc,
-                       a.velt, a.pk, a.slot, a.count, a.flags, n);
+#define KDK_ARGS c, a.pos, a.id, a.acc, a.velt, a.cell_start, a.velk, a.pk, a.slot, a.count, a.flags, a.dn, a.send[0], a.send[1]
+void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+    if (cap <= 0) return;
+    dim3 g((cap + BLK - 1) / BLK), b(BLK);
+    if (c.has_left || c.has_right) hipLaunchKernelGGL((k_kick_drift_key<true, true>), g, b, 0, st, KDK_ARGS);
+    else hipLaunchKernelGGL((k_kick_drift_key<true, false>), g, b, 0, st, KDK_ARGS);
 }
-void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int n) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_kick_drift_key<false>, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.id, a.acc,
-                       a.velt, a.pk, a.slot, a.count, a.flags, n);
+void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+    if (cap <= 0) return;
+    hipLaunchKernelGGL((k_kick_drift_key<false, false>), dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, KDK_ARGS);
+}
+#undef KDK_ARGS
+
+// slab mode: the records received from the two neighbours join the staging arrays behind the owned particles
+__global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__restrict__ recv_l,
+                                                const uint32_t *__restrict__ recv_r, float2 *__restrict__ velk,
+                                                float4 *__restrict__ pk, uint32_t *__restrict__ slot,
+                                                uint32_t *__restrict__ count, uint32_t *__restrict__ flags,
+                                                uint32_t *__restrict__ dn, int stage_cap) {
+    const int n_own = (int)dn[1];
+    const int nl = c.has_left ? min((int)recv_l[0], c.halo_cap) : 0;
+    const int nr = c.has_right ? min((int)recv_r[0], c.halo_cap) : 0;
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (t == 0) {
+        int total = n_own + nl + nr;
+        if (total > stage_cap) { atomicAdd(&flags[FLAG_CAPACITY], 1u); total = stage_cap; }
+        if ((c.has_left && (int)recv_l[0] > c.halo_cap) || (c.has_right && (int)recv_r[0] > c.halo_cap))
+            atomicAdd(&flags[FLAG_CAPACITY], 1u);
+        dn[0] = (uint32_t)total;
+    }
+    if (t >= nl + nr) return;
+    const int dst = n_own + t;
+    if (dst >= stage_cap) return;
+    const uint32_t *r = (t < nl) ? recv_l + HALO_HDR + (size_t)t * HALO_REC : recv_r + HALO_HDR + (size_t)(t - nl) * HALO_REC;
+    const float2 p = make_float2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    int row, col;
+    bool oob, bad;
+    cell_of(c, p.x, p.y, row, col, oob, bad);
+    const uint32_t key = (uint32_t)(col * c.rows + row);
+    pk[dst] = make_float4(p.x, p.y, __uint_as_float(r[4]), __uint_as_float(key));
+    velk[dst] = make_float2(__uint_as_float(r[2]), __uint_as_float(r[3]));
+    slot[dst] = atomicAdd(&count[key], 1u);
+    if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
+    else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
+}
+
+void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap) {
+    const int work = 2 * c.halo_cap;
+    hipLaunchKernelGGL(k_ingest, dim3((work + BLK - 1) / BLK > 0 ? (work + BLK - 1) / BLK : 1), dim3(BLK), 0, st, c, a.recv[0],
+                       a.recv[1], a.velk, a.pk, a.slot, a.count, a.flags, a.dn, stage_cap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -208,29 +283,29 @@ void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *cel
 
 // ------------------------------------------------------------------------------------------
 // P4: scatter to cell order.
-__global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, const float2 *__restrict__ velt,
+__global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, const float2 *__restrict__ velk,
                                                  const uint32_t *__restrict__ slot,
                                                  const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
                                                  float2 *__restrict__ vel, uint32_t *__restrict__ id,
-                                                 uint32_t *__restrict__ skey, int n) {
+                                                 uint32_t *__restrict__ skey, const uint32_t *__restrict__ dn) {
     int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= (int)dn[0]) return;
     float4 q = pk[i];
     const uint32_t key = __float_as_uint(q.w);
     uint32_t dst = cell_start[key] + slot[i];
     pos[dst] = make_float2(q.x, q.y);
-    vel[dst] = velt[i];
+    vel[dst] = velk[i];
     id[dst] = __float_as_uint(q.z);
     skey[dst] = key;        // sorted keys: the tile table of the tiled kernels is built from them
 }
 
-void launch_tile_table(hipStream_t st, const Consts &c, const Arrays &a, int n);   // sph_tiled.inc
+void launch_tile_table(hipStream_t st, const Consts &c, const Arrays &a, int cap);   // sph_tiled.inc
 
-void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int n) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_reorder, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, a.pk, a.velt, a.slot, a.cell_start, a.pos,
-                       a.vel, a.id, a.skey, n);
-    launch_tile_table(st, c, a, n);
+void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+    if (cap <= 0) return;
+    hipLaunchKernelGGL(k_reorder, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, a.pk, a.velk, a.slot, a.cell_start, a.pos,
+                       a.vel, a.id, a.skey, a.dn);
+    launch_tile_table(st, c, a, cap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -250,9 +325,10 @@ template <bool EOS>
 __global__ __launch_bounds__(BLK) void k_density_direct(Consts c, const float2 *__restrict__ pos,
                                                         const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
                                                         const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
-                                                        float2 *__restrict__ rp, float *__restrict__ prs, int n) {
+                                                        float2 *__restrict__ rp, float *__restrict__ prs,
+                                                        const uint32_t *__restrict__ dn) {
     int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= (int)dn[0]) return;
     float2 pi = pos[i];
     int row, col;
     bool oob, bad;
@@ -291,9 +367,10 @@ __global__ __launch_bounds__(BLK) void k_density_direct(Consts c, const float2 *
 
 // EOS alone (stage entry point): from the stored rho, or (from_prs) only refresh p/rho^2 from stored rho and p
 template <bool FROM_PRS>
-__global__ __launch_bounds__(BLK) void k_eos(Consts c, float2 *__restrict__ rp, float *__restrict__ prs, int n) {
+__global__ __launch_bounds__(BLK) void k_eos(Consts c, float2 *__restrict__ rp, float *__restrict__ prs,
+                                             const uint32_t *__restrict__ dn) {
     int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= (int)dn[0]) return;
     float rho = rp[i].x;
     if (FROM_PRS) {
         rp[i].y = prs[i] / (rho * rho);
@@ -305,11 +382,11 @@ __global__ __launch_bounds__(BLK) void k_eos(Consts c, float2 *__restrict__ rp, 
     }
 }
 
-void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int n, bool from_prs) {
-    if (n <= 0) return;
-    dim3 g((n + BLK - 1) / BLK), b(BLK);
-    if (from_prs) hipLaunchKernelGGL(k_eos<true>, g, b, 0, st, c, a.rp, a.prs, n);
-    else hipLaunchKernelGGL(k_eos<false>, g, b, 0, st, c, a.rp, a.prs, n);
+void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool from_prs) {
+    if (cap <= 0) return;
+    dim3 g((cap + BLK - 1) / BLK), b(BLK);
+    if (from_prs) hipLaunchKernelGGL(k_eos<true>, g, b, 0, st, c, a.rp, a.prs, a.dn);
+    else hipLaunchKernelGGL(k_eos<false>, g, b, 0, st, c, a.rp, a.prs, a.dn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -338,9 +415,9 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
                                                       const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
                                                       const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
                                                       const float2 *__restrict__ grav, float2 *__restrict__ acc,
-                                                      float2 *__restrict__ velt, int n) {
+                                                      float2 *__restrict__ velt, const uint32_t *__restrict__ dn) {
     int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= (int)dn[0]) return;
     float2 pi = pos[i], vi = vel[i], rpi = rp[i];
     int row, col;
     bool oob, bad;
@@ -389,29 +466,57 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
 
 namespace sph {
 
-void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int n, int mode, int variant) {
-    if (n <= 0) return;
-    if (variant == 0) { launch_density_tiled(st, c, a, n, mode); return; }
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant) {
+    if (cap <= 0) return;
+    if (variant == 0) { launch_density_tiled(st, c, a, cap, mode); return; }
     if (mode == DENS_MASKS_ONLY) return;      // the direct variant has no masks
-    dim3 g((n + BLK - 1) / BLK), b(BLK);
+    dim3 g((cap + BLK - 1) / BLK), b(BLK);
     if (mode == DENS_RHO_EOS)
         hipLaunchKernelGGL(k_density_direct<true>, g, b, 0, st, c, a.pos, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, n);
+                           a.rp, a.prs, a.dn);
     else
         hipLaunchKernelGGL(k_density_direct<false>, g, b, 0, st, c, a.pos, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, n);
+                           a.rp, a.prs, a.dn);
 }
 
-void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int n, bool kick, int variant) {
-    if (n <= 0) return;
-    if (variant == 0) { launch_force_tiled(st, c, a, n, kick); return; }
-    dim3 g((n + BLK - 1) / BLK), b(BLK);
+void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool kick, int variant) {
+    if (cap <= 0) return;
+    if (variant == 0) { launch_force_tiled(st, c, a, cap, kick); return; }
+    dim3 g((cap + BLK - 1) / BLK), b(BLK);
     if (kick)
         hipLaunchKernelGGL(k_force_direct<true>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.cell_start, a.bpos, a.bpsi,
-                           a.bcell_start, a.grav, a.acc, a.velt, n);
+                           a.bcell_start, a.grav, a.acc, a.velt, a.dn);
     else
         hipLaunchKernelGGL(k_force_direct<false>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.cell_start, a.bpos, a.bpsi,
-                           a.bcell_start, a.grav, a.acc, a.velt, n);
+                           a.bcell_start, a.grav, a.acc, a.velt, a.dn);
+}
+
+// slab mode read-back: the owned particles (sorted order) as compact AoS + their global ids (+ accelerations)
+__global__ __launch_bounds__(BLK) void k_export_owned(Consts c, const float2 *__restrict__ pos,
+                                                      const float2 *__restrict__ velt, const uint32_t *__restrict__ id,
+                                                      const float2 *__restrict__ rp, const float *__restrict__ prs,
+                                                      const float2 *__restrict__ acc, const uint32_t *__restrict__ cs,
+                                                      uint32_t *__restrict__ dn, sph_particle *__restrict__ out,
+                                                      uint32_t *__restrict__ ids, float *__restrict__ du,
+                                                      float *__restrict__ dv) {
+    const int beg = (int)cs[c.ghost * c.rows], n = (int)cs[(c.ghost + c.owned) * c.rows] - beg;
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (t == 0) dn[2] = (uint32_t)n;
+    if (t >= n) return;
+    const int i = beg + t;
+    sph_particle q;
+    q.x = pos[i].x; q.y = pos[i].y; q.u = velt[i].x; q.v = velt[i].y; q.m = c.m_fluid; q.rho = rp[i].x; q.p = prs[i];
+    out[t] = q;
+    ids[t] = id[i];
+    du[t] = acc[i].x;
+    dv[t] = acc[i].y;
+}
+
+void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int cap, sph_particle *out_dev, uint32_t *ids_dev,
+                         float *du, float *dv) {
+    if (cap <= 0) return;
+    hipLaunchKernelGGL(k_export_owned, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.velt, a.id, a.rp, a.prs,
+                       a.acc, a.cell_start, a.dn, out_dev, ids_dev, du, dv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -466,6 +571,17 @@ __global__ __launch_bounds__(BLK) void k_boundary_psi(Consts c, const float2 *__
         }
     }
     bpsi[i] = c.rho0 / (c.nf * s);      // psi = rho_0 / sum W   :259
+}
+
+__global__ __launch_bounds__(BLK) void k_boundary_gather_psi(const float *__restrict__ psi_in, const uint32_t *__restrict__ bid,
+                                                             float *__restrict__ bpsi, int nb) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= nb) return;
+    bpsi[i] = psi_in[bid[i]];
+}
+void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *psi_in, int nb) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_boundary_gather_psi, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, psi_in, a.bid, a.bpsi, nb);
 }
 
 void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in, uint32_t *key, uint32_t *slot,

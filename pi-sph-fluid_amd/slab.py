@@ -1,0 +1,233 @@
+"""Host side of the x-slab domain decomposition: one process per GPU.
+
+The reference has no distributed path.  Its particle loops (pi_sph_fluid.c:272, :311) shard by cell
+column: a slab owns the global cell columns [c0, c1) and keeps two ghost columns per side, so ONE
+exchange per step (after kick+drift) carries both the ghosts and the ownership migration.  This
+module is backend-agnostic host logic:
+
+  partition_columns()  column ranges with ~equal particle counts (quantiles of the per-column histogram)
+  local_subset()       the particles a slab starts with (owned + ghosts) and their global ids
+  GpuSlab              the C-ABI slab context (sph_create_slab ... sph_slab_read)
+  LocalTransport       in-process exchange between several slabs on one device (tests, 1 GPU)
+  TorchTransport       torch.distributed P2P (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" on CPU)
+  SlabRunner           step loop: begin -> exchange -> end
+
+Halo buffer format (include/sph.h): uint32 header[4] = {count,0,0,0} then records of 5 words
+{x, y, u, v, id}; fixed capacity, always sent whole (messages are 0.1-1 MB: latency-bound on xGMI).
+"""
+import ctypes as C
+
+import numpy as np
+
+HALO_HDR = 4
+HALO_REC = 5
+GHOST = 2
+
+
+def global_columns(prm, x):
+    """global cell column of positions x — the device's arithmetic (cell_of): (int)((x - x_min) * (1/cell)), f32."""
+    cell = np.float32(2) * np.float32(prm.h)
+    inv = np.float32(1.0) / cell
+    return ((np.asarray(x, np.float32) - np.float32(prm.x_min)) * inv).astype(np.int64)
+
+
+def grid_columns(prm):
+    cell = np.float32(2) * np.float32(prm.h)
+    return int((np.float32(prm.x_max) - np.float32(prm.x_min)) / cell) + 1
+
+
+def grid_rows(prm):
+    cell = np.float32(2) * np.float32(prm.h)
+    return int((np.float32(prm.y_max) - np.float32(prm.y_min)) / cell) + 1
+
+
+def partition_columns(prm, fluid, world, slack=64):
+    """[(c0, c1)] * world: contiguous column ranges holding ~equal numbers of particles.  Columns outside
+    [first occupied - slack, last occupied + slack] belong to no slab (a particle reaching them is reported
+    as out of domain), which keeps every local grid proportional to its fluid instead of to the dry box."""
+    cols = grid_columns(prm)
+    gc = np.clip(global_columns(prm, fluid["x"]), 0, cols - 1)
+    hist = np.bincount(gc, minlength=cols)
+    occ = np.nonzero(hist)[0]
+    lo = max(0, int(occ[0]) - slack)
+    hi = min(cols, int(occ[-1]) + 1 + slack)
+    cum = np.cumsum(hist)
+    total = int(cum[-1])
+    cuts = [lo]
+    for r in range(1, world):
+        target = total * r / world
+        c = int(np.searchsorted(cum, target)) + 1        # first column boundary at or past the quantile
+        c = max(c, cuts[-1] + 4)                           # a slab owns at least 4 columns
+        cuts.append(c)
+    cuts.append(hi)
+    for r in range(world - 1, 0, -1):                      # keep >= 4 columns walking back from the end
+        cuts[r] = min(cuts[r], cuts[r + 1] - 4)
+    if any(cuts[r + 1] - cuts[r] < 4 for r in range(world)) or cuts[0] < 0:
+        raise ValueError("scene too narrow for %d slabs" % world)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def local_subset(prm, fluid, c0, c1):
+    """particles of columns [c0 - 2, c1 + 2) and their global ids (index into `fluid`)."""
+    gc = global_columns(prm, fluid["x"])
+    ids = np.nonzero((gc >= c0 - GHOST) & (gc < c1 + GHOST))[0].astype(np.uint32)
+    return np.ascontiguousarray(fluid[ids]), ids
+
+
+def halo_words(capacity):
+    return HALO_HDR + HALO_REC * capacity
+
+
+def default_halo_capacity(prm):
+    return 64 * grid_rows(prm)
+
+
+class GpuSlab:
+    """One slab on one GPU through the C ABI (sph_create_slab ...)."""
+
+    def __init__(self, pkg, prm, fluid, boundary_all, c0, c1, has_left, has_right, gx=0.0, gy=-9.81, device=0,
+                 halo_capacity=0, particle_capacity=0):
+        self.pkg, self.L = pkg, pkg.hip_lib()
+        self.c0, self.c1 = c0, c1
+        loc, ids = local_subset(prm, fluid, c0, c1)
+        self.halo_capacity = halo_capacity or default_halo_capacity(prm)
+        self.particle_capacity = particle_capacity or (len(loc) + len(loc) // 4 + 2 * self.halo_capacity + 1024)
+        desc = pkg.SlabDesc(c0, c1, int(has_left), int(has_right), self.halo_capacity, self.particle_capacity)
+        boundary_all = np.ascontiguousarray(boundary_all, pkg.PARTICLE)
+        self.h = C.c_void_p()
+        rc = self.L.sph_create_slab(C.byref(self.h), C.byref(prm), C.byref(desc), loc.ctypes.data_as(C.c_void_p),
+                                    ids.ctypes.data_as(C.c_void_p), len(loc), boundary_all.ctypes.data_as(C.c_void_p),
+                                    len(boundary_all), gx, gy, device)
+        if rc:
+            msg = self.L.sph_last_error(self.h).decode() if self.h else "sph_create_slab failed"
+            self.close()
+            raise pkg.SphError(rc, msg)
+        self.words = halo_words(self.halo_capacity)
+        self._torch_bufs = None
+
+    def _chk(self, rc):
+        if rc:
+            raise self.pkg.SphError(rc, self.L.sph_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step_begin(self, gx, gy):
+        self._chk(self.L.sph_slab_step_begin(self.h, gx, gy))
+
+    def step_end(self):
+        self._chk(self.L.sph_slab_step_end(self.h))
+
+    def sync(self):
+        self._chk(self.L.sph_sync(self.h))
+
+    def set_stream(self, hip_stream):
+        self._chk(self.L.sph_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    # host-staged transport
+    def copy_out(self, side):
+        buf = np.zeros(self.words, np.uint32)
+        self._chk(self.L.sph_slab_copy_out(self.h, side, buf.ctypes.data_as(C.c_void_p)))
+        return buf
+
+    def copy_in(self, side, buf):
+        buf = np.ascontiguousarray(buf, np.uint32)
+        assert len(buf) == self.words
+        self._chk(self.L.sph_slab_copy_in(self.h, side, buf.ctypes.data_as(C.c_void_p)))
+
+    # device-resident transport: torch owns the buffers, the library packs into / ingests from them
+    def halo_tensors(self, torch, device):
+        if self._torch_bufs is None:
+            bufs = [torch.zeros(self.words, dtype=torch.int32, device=device) for _ in range(4)]
+            self._chk(self.L.sph_slab_set_buffers(self.h, *[C.c_void_p(b.data_ptr()) for b in bufs], self.words * 4))
+            self._torch_bufs = bufs
+        return self._torch_bufs      # send_left, send_right, recv_left, recv_right
+
+    def read(self):
+        """owned particles, their global ids and accelerations."""
+        cap = self.particle_capacity
+        out = np.zeros(cap, self.pkg.PARTICLE)
+        ids = np.zeros(cap, np.uint32)
+        du, dv = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        n = C.c_int()
+        self._chk(self.L.sph_slab_read(self.h, out.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                                       du.ctypes.data_as(C.c_void_p), dv.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        k = n.value
+        return out[:k], ids[:k], du[:k], dv[:k]
+
+    def counts(self):
+        a, b = C.c_int(), C.c_int()
+        self._chk(self.L.sph_slab_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+class LocalTransport:
+    """All slabs live in this process (one device): what slab r sends right is what slab r+1 receives left."""
+
+    def __init__(self, slabs):
+        self.slabs = slabs
+
+    def exchange(self):
+        s = self.slabs
+        for r in range(len(s) - 1):
+            right_of_r = s[r].copy_out(1)
+            left_of_next = s[r + 1].copy_out(0)
+            s[r + 1].copy_in(0, right_of_r)
+            s[r].copy_in(1, left_of_next)
+
+
+class TorchTransport:
+    """One slab per process; neighbours exchange whole halo buffers by torch.distributed P2P
+    (backend "nccl" is RCCL over xGMI; "gloo" on CPU).  A slab has at most two neighbours, so only
+    two of a GPU's seven xGMI links carry traffic and the messages are latency-bound."""
+
+    def __init__(self, torch, dist, slab, rank, world, device):
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.send_l, self.send_r, self.recv_l, self.recv_r = slab.halo_tensors(torch, device)
+
+    def exchange(self):
+        d, ops = self.dist, []
+        if self.rank > 0:
+            ops.append(d.P2POp(d.isend, self.send_l, self.rank - 1))
+            ops.append(d.P2POp(d.irecv, self.recv_l, self.rank - 1))
+        if self.rank < self.world - 1:
+            ops.append(d.P2POp(d.isend, self.send_r, self.rank + 1))
+            ops.append(d.P2POp(d.irecv, self.recv_r, self.rank + 1))
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+
+
+class SlabRunner:
+    """nsteps of: kick/drift + halo pack -> exchange -> ingest + sort + density + force (pi_sph_fluid.c:612-641)."""
+
+    def __init__(self, slabs, transport):
+        self.slabs = slabs if isinstance(slabs, (list, tuple)) else [slabs]
+        self.transport = transport
+
+    def step(self, nsteps=1, gx=0.0, gy=-9.81):
+        for _ in range(nsteps):
+            for s in self.slabs:
+                s.step_begin(gx, gy)
+            self.transport.exchange()
+            for s in self.slabs:
+                s.step_end()
+
+    def gather_local(self, n_total, particle_dtype):
+        """all slabs of THIS process merged back into original order (ids index the global arrays)."""
+        out = np.zeros(n_total, particle_dtype)
+        du, dv = np.zeros(n_total, np.float32), np.zeros(n_total, np.float32)
+        seen = np.zeros(n_total, np.int32)
+        for s in self.slabs:
+            p, ids, a, b = s.read()
+            out[ids], du[ids], dv[ids] = p, a, b
+            seen[ids] += 1
+        return out, du, dv, seen

@@ -1,0 +1,94 @@
+"""Slab decomposition on a real MI355X: several slab contexts on ONE device (host-staged exchange through the
+C ABI) must reproduce the single-context run (gate G7: N-GPU == 1-GPU), with every particle owned exactly once."""
+import numpy as np
+import pytest
+
+from conftest import GX, GY, boundary_particles, load_golden, particles
+
+pytestmark = pytest.mark.gpu
+
+
+def build(sph, prm, f, b, world, slack=8):
+    parts = sph.slab.partition_columns(prm, f, world, slack=slack)
+    slabs = [sph.slab.GpuSlab(sph, prm, f, b, c0, c1, r > 0, r < world - 1, GX, GY) for r, (c0, c1) in enumerate(parts)]
+    return slabs, sph.slab.SlabRunner(slabs, sph.slab.LocalTransport(slabs))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_developed_block_slabs_vs_single(sph, orc, world):
+    g = load_golden("block.npz")
+    prm = sph.default_params(tuple(g["box"]))
+    f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))
+    b = boundary_particles(orc, g["boundary_xy"])
+    slabs, runner = build(sph, prm, f, b, world)
+    # t = 0: rho, p, a of the owned particles equal the single context's
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ref0 = ctx.read_particles()
+        rdu0, rdv0 = ctx.read_accel()
+        out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+        assert np.all(seen == 1)
+        assert np.array_equal(out["x"], ref0["x"])
+        assert np.max(np.abs(out["rho"] - ref0["rho"]) / ref0["rho"]) <= 1e-6
+        assert np.max(np.hypot(du - rdu0, dv - rdv0)) <= 1e-3 * (np.hypot(rdu0, rdv0).max())
+        ids0 = [s.read()[1].copy() for s in slabs]
+        # staged: a missing ghost or lost migrant would show as O(1e-2) in rho after ONE step; later the two runs
+        # differ by summation order only, amplified by the chaotic developed flow (|v| up to 20 m/s)
+        done = 0
+        for k, tol_x, tol_rho in [(1, 2e-6, 1e-5), (20, 2e-5, 2e-4), (150, 2e-3, 2e-2)]:
+            ctx.step(k - done, GX, GY)
+            ctx.sync()
+            runner.step(k - done, GX, GY)
+            done = k
+            ref = ctx.read_particles()
+            out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+            assert np.all(seen == 1), k
+            dx = max(np.abs(out["x"] - ref["x"]).max(), np.abs(out["y"] - ref["y"]).max())
+            drho = np.max(np.abs(out["rho"] - ref["rho"]) / ref["rho"])
+            assert dx <= tol_x and drho <= tol_rho, (k, dx, drho)
+    for s in slabs:
+        s.sync()
+    migrated = sum(len(set(s.read()[1].tolist()) - set(i0.tolist())) for s, i0 in zip(slabs, ids0))
+    assert migrated > 0
+    for s in slabs:
+        s.close()
+
+
+def test_lattice_dam_break_slabs_vs_single_large(sph):
+    """300 000 particles, 4 slabs, 40 steps from the lattice: tight agreement (summation order only)."""
+    prm, f, b = sph.scene_block((0.0, 200.0, 0.0, 40.0), 0.3, 0.3, 1000, 300)
+    slabs, runner = build(sph, prm, f, b, 4, slack=16)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.step(40, GX, GY)
+        ctx.sync()
+        ref = ctx.read_particles()
+    runner.step(40, GX, GY)
+    out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+    assert np.all(seen == 1)
+    assert max(np.abs(out["x"] - ref["x"]).max(), np.abs(out["y"] - ref["y"]).max()) <= 1e-5
+    assert np.max(np.abs(out["rho"] - ref["rho"]) / ref["rho"]) <= 1e-5
+    n_loc, n_own = slabs[1].counts()
+    assert n_own < n_loc <= slabs[1].particle_capacity       # ghosts present
+    for s in slabs:
+        s.close()
+
+
+def test_slab_errors(sph):
+    prm, f, b = sph.scene_block((0.0, 40.0, 0.0, 8.0), 0.3, 0.3, 240, 60)
+    s = sph.slab.GpuSlab(sph, prm, f, b, 0, 60, False, True, GX, GY)
+    L = sph.hip_lib()
+    assert L.sph_step(s.h, 0.0, -9.81, 1) == sph.SPH_E_STATE          # single-GPU entry point on a slab
+    assert L.sph_slab_step_end(s.h) == sph.SPH_E_STATE                # end without begin
+    s.step_begin(GX, GY)
+    assert L.sph_slab_step_begin(s.h, 0.0, -9.81) == sph.SPH_E_STATE
+    s.step_end()
+    s.close()
+    with pytest.raises(sph.SphError):
+        sph.slab.GpuSlab(sph, prm, f, b, 10, 12, True, True, GX, GY)   # < 4 owned columns
+    # a halo buffer that is too small is reported, not overrun
+    t = sph.slab.GpuSlab(sph, prm, f, b, 0, 60, False, True, GX, GY, halo_capacity=16)
+    t.step_begin(GX, GY)
+    t.step_end()
+    with pytest.raises(sph.SphError) as e:
+        t.sync()
+    assert e.value.code == sph.SPH_E_CAPACITY
+    t.close()
