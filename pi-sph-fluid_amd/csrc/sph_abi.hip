@@ -289,7 +289,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
 #define ALLOC(ptr, cnt) if ((rc = dalloc(ctx, &(ptr), (cnt))) != SPH_OK) return rc
     ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
     ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.hitmask, 3 * n); ALLOC(a.skey, n);
-    ALLOC(a.tiles, 10 * ((n + 255) / 256 + 1)); ALLOC(a.slot, n > nb ? n : nb);
+    ALLOC(a.tiles, 11 * ((n + 255) / 256 + 9)); ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
     ALLOC(a.bpos, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);

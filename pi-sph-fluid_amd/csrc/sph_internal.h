@@ -53,7 +53,7 @@ struct Arrays {
     float *prs;        // p
     float2 *acc;       // du_dt, dv_dt
     uint32_t *skey;    // sorted cell keys
-    uint32_t *tiles;   // one 40-byte TileInfo record per 256-particle workgroup (sph_tiled.inc)
+    uint32_t *tiles;   // one 44-byte TileInfo record per 256-particle workgroup (sph_tiled.inc)
     uint32_t *hitmask; // 3 x n: per particle, per candidate segment, bit k = candidate k is a neighbour (density -> force)
     // staging (T)
     float4 *pk;        // x, y, id bits, cell key bits (after kick/drift, before the sort)

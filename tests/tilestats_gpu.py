@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sph = importlib.import_module("pi-sph-fluid_amd")
 warm = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-prm, f, b = sph.dam_break(1)
+prm, f, b = sph.scene(sys.argv[2]) if len(sys.argv) > 2 else sph.dam_break(1)
 ctx = sph.Context(prm, f, b)
 ctx.step(warm); ctx.sync()
 p = ctx.read_particles()
@@ -19,6 +19,7 @@ cs = np.searchsorted(key, np.arange(ncell + 1))
 nb = (n + 255) // 256
 klo = key[np.arange(nb) * 256]; khi = key[np.minimum(np.arange(nb) * 256 + 255, n - 1)]
 tot = np.zeros(nb, np.int64)
+HALF = 127
 for s in range(3):
     lo = klo + (s - 1) * rows - 1; hi = khi + (s - 1) * rows + 1
     ok = (hi >= 0) & (lo <= ncell - 1)
