@@ -70,6 +70,28 @@ def main():
                 rd, wr = 2 * fs * 1024 / 1e6, ws * 1024 / 1e6
                 lines.append("| %s | %.0f | %.0f | %.2f | %.2f | %.2f |" % (kn, fs, ws, rd, wr, rd + wr))
         lines.append("")
+    # per-launch HBM traffic of the step kernels in bench.py's naming (read side doubled, see above)
+    names = {"k_kick_drift_key<true, false>": "kick_drift_key", "k_reorder": "reorder", "k_density_tiled<1>": "density_eos",
+             "k_force_tiled<true, 0>": "force_kick", "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply",
+             "k_tile_table": "tile_table"}
+    traffic = {}
+    for kn, bn in names.items():
+        cs = merged.get(kn, {})
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            traffic[bn] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
+    if len(sys.argv) > 3 and traffic:
+        import json
+        path, workload = sys.argv[3], (sys.argv[4] if len(sys.argv) > 4 else "cfg2")
+        try:
+            allt = json.load(open(path))
+        except Exception:
+            allt = {}
+        allt[workload] = traffic
+        allt["_note"] = ("HBM-side bytes per launch from rocprofv3 PMC passes (profiles/collect.sh): 2 x FETCH_SIZE KiB + "
+                         "WRITE_SIZE KiB; the x2 is the gfx950 correction for wide coalesced reads "
+                         "(MI355X_MICROARCH.md, HBM) and is an upper bound where reads are 8 B/lane; "
+                         "Infinity-Cache hits are counted")
+        json.dump(allt, open(path, "w"), indent=1)
     text = "\n".join(lines)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(text + "\n")
