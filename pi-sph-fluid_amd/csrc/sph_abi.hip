@@ -129,7 +129,7 @@ void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
     if (ev) (void)hipEventRecord(ev[SPH_K_KICK_DRIFT_KEY], st);
     launch_kick_drift_key(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_SCAN_REDUCE], st);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.cell_start, ctx->a.block_sums, ev ? ev[SPH_K_SCAN_APPLY] : nullptr);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ev ? ev[SPH_K_SCAN_APPLY] : nullptr);
     if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
@@ -169,7 +169,7 @@ bool ensure_graph(sph_ctx *ctx) {
 int resort_state(sph_ctx *ctx) {
     hipStream_t st = ctx->stream;
     launch_key_only(st, ctx->c, ctx->a, ctx->cap);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.cell_start, ctx->a.block_sums, nullptr);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, nullptr);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     HIPCHK(ctx, hipMemcpyAsync(ctx->a.velt, ctx->a.vel, sizeof(float2) * (size_t)ctx->cap, hipMemcpyDeviceToDevice, st));
     return SPH_OK;
@@ -291,6 +291,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.hitmask, 3 * n); ALLOC(a.skey, n);
     ALLOC(a.tiles, 11 * ((n + 255) / 256 + 9)); ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
+    ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 64 * 128);
@@ -307,6 +308,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
 #undef ALLOC
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.acc, 0, (n ? n : 1) * sizeof(float2), st));
     if (slab)
@@ -322,8 +324,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     std::vector<float> hpsi(nb ? nb : 1);
     for (size_t i = 0; i < nb; i++) { hb[i] = make_float2(boundary[i].x, boundary[i].y); hpsi[i] = boundary[i].m; }
     HIPCHK(ctx, hipMemcpyAsync(bpos_in, hb.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
-    launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.flags, n_boundary);
-    launch_scan(st, ctx->c, a.count, a.bcell_start, a.block_sums, nullptr);
+    launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.dirty, a.flags, n_boundary);
+    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, nullptr);
     launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary);
     if (psi_given) {
         // psi was computed on the full wall set (a slab sees only its part of the walls): scatter it to bin order
@@ -621,7 +623,7 @@ int sph_slab_step_end(sph_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     launch_ingest(st, ctx->c, ctx->a, ctx->cap);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.cell_start, ctx->a.block_sums, nullptr);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, nullptr);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
     launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);

@@ -62,6 +62,7 @@ struct Arrays {
     uint32_t *slot;    // arrival rank of the particle inside its cell
     // grid
     uint32_t *count;      // per-cell histogram (zero between sorts)
+    uint32_t *dirty;      // one flag per scan tile (2048 cells): a histogram atomic touched it since the last scan
     uint32_t *cell_start; // n_cells + 1, exclusive scan of count
     uint32_t *block_sums; // scan scratch
     // boundary, sorted once at init
@@ -98,8 +99,8 @@ void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_c
 // slab mode: owned particles (sorted order) -> compact AoS + ids; count left in dn[1]... see sph_abi.hip
 void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int cap, sph_particle *out_dev, uint32_t *ids_dev,
                          float *du, float *dv);
-void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *cell_start, uint32_t *block_sums,
-                 hipEvent_t mid /* optional: recorded between the two scan kernels */);
+void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
+                 uint32_t *block_sums, hipEvent_t mid /* optional: recorded between the two scan kernels */);
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 // variant: 0 = LDS-tiled (default), 1 = direct global loads
 // mode: what the density pass writes.  The tiled force kernel consumes the neighbour masks the tiled
@@ -111,7 +112,7 @@ void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool 
 void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool kick, int variant);
 // boundary init: bin + pseudo-mass (:600-601, :242-261)
 void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in, uint32_t *key, uint32_t *slot,
-                         uint32_t *count, uint32_t *flags, int nb);
+                         uint32_t *count, uint32_t *dirty, uint32_t *flags, int nb);
 void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
                              const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb);
 void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb);

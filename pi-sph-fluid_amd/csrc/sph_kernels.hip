@@ -83,8 +83,9 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
                                                         const float2 *__restrict__ velt, const uint32_t *__restrict__ cs,
                                                         float2 *__restrict__ velk, float4 *__restrict__ pk,
                                                         uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
-                                                        uint32_t *__restrict__ flags, uint32_t *__restrict__ dn,
-                                                        uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r) {
+                                                        uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
+                                                        uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
+                                                        uint32_t *__restrict__ send_r) {
     const int t = blockIdx.x * BLK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int src0 = 0, n;
@@ -131,7 +132,10 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
         int next = above ? start + __builtin_ffsll((long long)above) : 64;
         next = min(next, 64 - __builtin_clzll(am));                          // active lanes are a prefix of the wave
         uint32_t base = 0;
-        if (lane == start) base = atomicAdd(&count[key], (uint32_t)(next - start));
+        if (lane == start) {
+            base = atomicAdd(&count[key], (uint32_t)(next - start));
+            dirty[key / SCAN_TILE] = 1u;      // the scan skips histogram tiles nobody touched (most of a dry box)
+        }
         base = __shfl(base, start, 64);
         slot[t] = base + (uint32_t)(lane - start);
         pk[t] = make_float4(p.x, p.y, __uint_as_float(pid), __uint_as_float(key));
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
     }
 }
 
-#define KDK_ARGS c, a.pos, a.id, a.acc, a.velt, a.cell_start, a.velk, a.pk, a.slot, a.count, a.flags, a.dn, a.send[0], a.send[1]
+#define KDK_ARGS c, a.pos, a.id, a.acc, a.velt, a.cell_start, a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.dn, a.send[0], a.send[1]
 void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     if (cap <= 0) return;
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
@@ -162,8 +166,8 @@ void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap) 
 __global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__restrict__ recv_l,
                                                 const uint32_t *__restrict__ recv_r, float2 *__restrict__ velk,
                                                 float4 *__restrict__ pk, uint32_t *__restrict__ slot,
-                                                uint32_t *__restrict__ count, uint32_t *__restrict__ flags,
-                                                uint32_t *__restrict__ dn, int stage_cap) {
+                                                uint32_t *__restrict__ count, uint32_t *__restrict__ dirty,
+                                                uint32_t *__restrict__ flags, uint32_t *__restrict__ dn, int stage_cap) {
     const int n_own = (int)dn[1];
     const int nl = c.has_left ? min((int)recv_l[0], c.halo_cap) : 0;
     const int nr = c.has_right ? min((int)recv_r[0], c.halo_cap) : 0;
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__rest
     pk[dst] = make_float4(p.x, p.y, __uint_as_float(r[4]), __uint_as_float(key));
     velk[dst] = make_float2(__uint_as_float(r[2]), __uint_as_float(r[3]));
     slot[dst] = atomicAdd(&count[key], 1u);
+    dirty[key / SCAN_TILE] = 1u;
     if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
     else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
 }
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__rest
 void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap) {
     const int work = 2 * c.halo_cap;
     hipLaunchKernelGGL(k_ingest, dim3((work + BLK - 1) / BLK > 0 ? (work + BLK - 1) / BLK : 1), dim3(BLK), 0, st, c, a.recv[0],
-                       a.recv[1], a.velk, a.pk, a.slot, a.count, a.flags, a.dn, stage_cap);
+                       a.recv[1], a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.dn, stage_cap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -221,8 +226,13 @@ DEV uint32_t block_sum_256(uint32_t v, uint32_t *lds4) {
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__restrict__ count,
+                                                            const uint32_t *__restrict__ dirty,
                                                             uint32_t *__restrict__ block_sums) {
     __shared__ uint32_t red[4];
+    if (dirty[blockIdx.x] == 0u) {      // untouched since it was last zeroed: all counts are 0
+        if (threadIdx.x == 0) block_sums[blockIdx.x] = 0u;
+        return;
+    }
     const uint4 *src = reinterpret_cast<const uint4 *>(count + (size_t)blockIdx.x * SCAN_TILE) + threadIdx.x * 2;
     uint4 a = src[0], b = src[1];
     uint32_t s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__re
 
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict__ count,
                                                            const uint32_t *__restrict__ block_sums,
+                                                           uint32_t *__restrict__ dirty,
                                                            uint32_t *__restrict__ cell_start, int n_items) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t wave_tot[4];
@@ -241,6 +252,20 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
     off = block_sum_256(off, red);
 
     size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    if (dirty[blockIdx.x] == 0u) {      // empty tile: every cell starts at the running offset; nothing to read or zero
+        if (base + SCAN_ITEMS <= (size_t)n_items) {
+            uint4 *dst = reinterpret_cast<uint4 *>(cell_start + base);
+            dst[0] = make_uint4(off, off, off, off);
+            dst[1] = make_uint4(off, off, off, off);
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; k++)
+                if (base + k < (size_t)n_items) cell_start[base + k] = off;
+        }
+        return;
+    }
+    __syncthreads();                    // every thread has read the flag before it is cleared
+    if (threadIdx.x == 0) dirty[blockIdx.x] = 0u;
     uint4 *src = reinterpret_cast<uint4 *>(count + base);
     uint4 a = src[0], b = src[1];
     uint32_t v[SCAN_ITEMS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -272,13 +297,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
     }
 }
 
-void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *cell_start, uint32_t *block_sums,
-                 hipEvent_t mid) {
+void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
+                 uint32_t *block_sums, hipEvent_t mid) {
     int n_items = c.n_cells + 1;
     int tiles = (n_items + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, dirty, block_sums);
     if (mid) (void)hipEventRecord(mid, st);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums, cell_start, n_items);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums, dirty, cell_start, n_items);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -523,7 +548,8 @@ void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int c
 // boundary: bin once (:600) and Akinci pseudo-mass (:242-261)
 __global__ __launch_bounds__(BLK) void k_boundary_key(Consts c, const float2 *__restrict__ bpos_in,
                                                       uint32_t *__restrict__ key, uint32_t *__restrict__ slot,
-                                                      uint32_t *__restrict__ count, uint32_t *__restrict__ flags, int nb) {
+                                                      uint32_t *__restrict__ count, uint32_t *__restrict__ dirty,
+                                                      uint32_t *__restrict__ flags, int nb) {
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= nb) return;
     float2 p = bpos_in[i];
@@ -533,6 +559,7 @@ __global__ __launch_bounds__(BLK) void k_boundary_key(Consts c, const float2 *__
     uint32_t k = (uint32_t)(col * c.rows + row);
     key[i] = k;
     slot[i] = atomicAdd(&count[k], 1u);
+    dirty[k / SCAN_TILE] = 1u;
     if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
     else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
 }
@@ -585,9 +612,10 @@ void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *ps
 }
 
 void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in, uint32_t *key, uint32_t *slot,
-                         uint32_t *count, uint32_t *flags, int nb) {
+                         uint32_t *count, uint32_t *dirty, uint32_t *flags, int nb) {
     if (nb <= 0) return;
-    hipLaunchKernelGGL(k_boundary_key, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, c, bpos_in, key, slot, count, flags, nb);
+    hipLaunchKernelGGL(k_boundary_key, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, c, bpos_in, key, slot, count, dirty,
+                       flags, nb);
 }
 void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
                              const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb) {
