@@ -40,6 +40,8 @@ struct sph_ctx {
     size_t bytes = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
+    hipGraph_t sgraph[2] = {nullptr, nullptr};       // slab mode: [0] = step_begin, [1] = step_end
+    hipGraphExec_t sgexec[2] = {nullptr, nullptr};
     bool use_graph = true;
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
     long long oob_total = 0, nan_total = 0;
@@ -142,6 +144,54 @@ void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
 void drop_graph(sph_ctx *ctx) {
     if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
     if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+    for (int k = 0; k < 2; k++) {
+        if (ctx->sgexec[k]) { (void)hipGraphExecDestroy(ctx->sgexec[k]); ctx->sgexec[k] = nullptr; }
+        if (ctx->sgraph[k]) { (void)hipGraphDestroy(ctx->sgraph[k]); ctx->sgraph[k] = nullptr; }
+    }
+}
+
+// the two halves of a slab step (everything except the gravity upload, which carries this call's arguments)
+int enqueue_slab_half(sph_ctx *ctx, int half) {
+    hipStream_t st = ctx->stream;
+    if (half == 0) {
+        for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, HALO_HDR * sizeof(uint32_t), st));
+        launch_kick_drift_key(st, ctx->c, ctx->a, ctx->cap);
+    } else {
+        launch_ingest(st, ctx->c, ctx->a, ctx->cap);
+        launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, nullptr);
+        launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+        launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
+        launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
+    }
+    return SPH_OK;
+}
+
+// Measured on MI355X: replaying two short graphs per step is SLOWER than ~11 eager launches (4622 vs 5417 steps/s at
+// 2M particles: hipGraphLaunch's fixed cost, MI355X_MICROARCH.md "graph-replay-floor"), so slab halves are launched
+// eagerly unless SPH_SLAB_GRAPH=1.  (sph_step's single graph per step does pay: the host loop is in C.)
+int run_slab_half(sph_ctx *ctx, int half) {
+    static const bool want_graph = getenv("SPH_SLAB_GRAPH") && getenv("SPH_SLAB_GRAPH")[0] == '1';
+    if (!want_graph) return enqueue_slab_half(ctx, half);
+    if (ctx->use_graph && !ctx->sgexec[half]) {
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            (void)enqueue_slab_half(ctx, half);
+            hipError_t e = hipStreamEndCapture(ctx->stream, &ctx->sgraph[half]);
+            if (e == hipSuccess) e = hipGraphInstantiate(&ctx->sgexec[half], ctx->sgraph[half], nullptr, nullptr, 0);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                drop_graph(ctx);
+                ctx->use_graph = false;
+            }
+        } else {
+            (void)hipGetLastError();
+            ctx->use_graph = false;
+        }
+    }
+    if (ctx->use_graph && ctx->sgexec[half]) {
+        HIPCHK(ctx, hipGraphLaunch(ctx->sgexec[half], ctx->stream));
+        return SPH_OK;
+    }
+    return enqueue_slab_half(ctx, half);
 }
 
 // capture one step into a graph (launch-latency bound at small N; replay costs one submission)
@@ -610,8 +660,8 @@ int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     launch_set_gravity(st, ctx->a, gx, gy);
-    for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, HALO_HDR * sizeof(uint32_t), st));
-    launch_kick_drift_key(st, ctx->c, ctx->a, ctx->cap);
+    int rc = run_slab_half(ctx, 0);
+    if (rc) return rc;
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_mid_step = true;
     return SPH_OK;
@@ -621,12 +671,8 @@ int sph_slab_step_end(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     if (!ctx->slab || !ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_begin");
     (void)hipSetDevice(ctx->device);
-    hipStream_t st = ctx->stream;
-    launch_ingest(st, ctx->c, ctx->a, ctx->cap);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, nullptr);
-    launch_reorder(st, ctx->c, ctx->a, ctx->cap);
-    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
-    launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
+    int rc = run_slab_half(ctx, 1);
+    if (rc) return rc;
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_mid_step = false;
     return SPH_OK;
@@ -648,6 +694,7 @@ int sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void *
     if (ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_set_buffers mid-step");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graph(ctx);          // the halo buffer addresses are baked into the captured step graphs
     ctx->a.send[0] = static_cast<uint32_t *>(send_left);
     ctx->a.send[1] = static_cast<uint32_t *>(send_right);
     ctx->a.recv[0] = static_cast<uint32_t *>(recv_left);
