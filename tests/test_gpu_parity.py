@@ -316,3 +316,97 @@ def test_metaballs(sph, orc, k):
         # pixels whose field value is within rounding of the threshold may flip; everything else is exact
         assert np.count_nonzero(got != exp) <= 2
         assert exp.sum() > 100
+
+
+def _orc_params_from(oracle, prm):
+    p = oracle.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
+    for k in ("r", "h", "rho0", "c", "g", "dt", "vol"):
+        setattr(p, k, getattr(prm, k))
+    p.alpha, p.eps, p.k1, p.k2 = float(prm.alpha), float(prm.eps), float(prm.k1), float(prm.k2)
+    return p
+
+
+@pytest.mark.parametrize("r,c_sound,alpha,k1", [(0.05, 300.0, 0.02, 0.05), (0.11, 600.0, 0.005, 0.2)])
+def test_non_default_parameters(sph, orc, oracle, r, c_sound, alpha, k1):
+    """every constant of pi_sph_fluid.c:11-20, :325-334 is a run-time parameter: other spacing, sound speed,
+    viscosity and artificial-pressure strength against the oracle evaluated with the same parameters."""
+    prm = sph.default_params((0.0, 10.0, 0.0, 5.0))
+    prm.r = r
+    prm.h = np.float32(r) * np.float32(1.3)
+    prm.c = c_sound
+    prm.dt = np.float32(prm.h) / np.float32(c_sound)
+    prm.vol = np.float32(0.57) * np.float32(prm.h) * np.float32(prm.h)
+    prm.alpha, prm.k1 = alpha, k1
+    nx, ny = int(4.0 / r), int(2.0 / r)
+    L = sph.host_lib()
+    import ctypes as C
+    f = np.zeros(nx * ny, sph.PARTICLE)
+    assert L.sph_scene_block(C.byref(prm), 4 * r, 4 * r, nx, ny, f.ctypes.data_as(C.c_void_p), len(f)) == len(f)
+    nb = L.sph_scene_walls(C.byref(prm), 0, None, 0)
+    b = np.zeros(nb, sph.PARTICLE)
+    L.sph_scene_walls(C.byref(prm), 0, b.ctypes.data_as(C.c_void_p), nb)
+    rng = np.random.default_rng(11)
+    f["u"] = rng.normal(0, 1.0, len(f)).astype(np.float32)
+    f["v"] = rng.normal(0, 1.0, len(f)).astype(np.float32)
+    p = _orc_params_from(oracle, prm)
+    of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()
+    oracle.psi(p, ob)
+    du, dv, sa = oracle.eval(p, of, ob, GX, GY, want_sum_abs=True)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        assert ctx.grid_dims() == oracle.grid_dims(p)
+        gb = ctx.read_boundary()
+        assert np.max(np.abs(gb["m"] - ob["m"]) / ob["m"]) <= TOL
+        got = ctx.read_particles()
+        assert np.max(np.abs(got["rho"] - of["rho"]) / of["rho"]) <= TOL
+        ctx.upload_state(of)
+        ctx.eval_pressure()
+        Bp = float(np.float32(c_sound) * np.float32(c_sound) * np.float32(1000.0) / np.float32(7))
+        assert np.max(np.abs(ctx.read_particles()["p"] - of["p"]) / (of["p"] + Bp)) <= TOL
+        ctx.upload_state(of)
+        ctx.eval_accel(GX, GY)
+        gdu, gdv = ctx.read_accel()
+        assert np.max(np.hypot(gdu - du, gdv - dv) / (sa + G)) <= TOL
+        ctx.upload_state(f)
+        ctx.eval_density(); ctx.eval_pressure(); ctx.eval_accel(GX, GY)
+        ctx.step(40, GX, GY)
+        ctx.sync()
+        got = ctx.read_particles()
+    oracle.steps(p, of, ob, GX, GY, du, dv, 40)
+    assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_clusters_vs_oracle(sph, orc, oracle, seed):
+    """irregular inputs: clumps of very different density, empty regions, particles on cell edges and tile sizes
+    that force every staging mode (one window, two windows, sparse) and the oversized-tile fallback."""
+    rng = np.random.default_rng(seed)
+    box = (0.0, 30.0, 0.0, 12.0)
+    prm, _, b = sph.scene_block(box, 0.3, 0.3, 1, 1)
+    pts = []
+    for _ in range(12):                                    # gaussian clumps, some very dense
+        cx, cy = rng.uniform(2, 28), rng.uniform(2, 10)
+        n, s = int(rng.integers(200, 1500)), rng.uniform(0.4, 1.5)      # up to ~300 neighbours (oracle scratch: 512)
+        pts.append(np.stack([rng.normal(cx, s, n), rng.normal(cy, s * 0.6, n)], 1))
+    pts.append(np.stack([rng.uniform(0.2, 29.8, 3000), rng.uniform(0.2, 11.8, 3000)], 1))      # sparse spray
+    cell = 0.195000008
+    edge = np.stack([np.round(rng.uniform(1, 29, 400) / cell) * cell, rng.uniform(1, 11, 400)], 1)   # on cell edges
+    pts.append(edge)
+    xy = np.concatenate(pts).astype(np.float32)
+    xy = xy[(xy[:, 0] > 0.1) & (xy[:, 0] < 29.9) & (xy[:, 1] > 0.1) & (xy[:, 1] < 11.9)]
+    f = particles(orc, np.concatenate([xy, rng.normal(0, 2, xy.shape).astype(np.float32)], 1), m_fluid(prm))
+    p = oracle.params(box)
+    ob = b.view(orc.PARTICLE).copy()
+    oracle.psi(p, ob)
+    of = f.copy()
+    du, dv, sa = oracle.eval(p, of, ob, GX, GY, want_sum_abs=True)
+    for variant in (0, 1):
+        with sph.Context(prm, f, b, GX, GY) as ctx:
+            ctx.set_variant(variant)
+            ctx.upload_state(f)
+            ctx.eval_density()
+            got = ctx.read_particles()
+            assert np.max(np.abs(got["rho"] - of["rho"]) / of["rho"]) <= TOL, variant
+            ctx.upload_state(of)
+            ctx.eval_accel(GX, GY)
+            gdu, gdv = ctx.read_accel()
+            assert np.max(np.hypot(gdu - du, gdv - dv) / (sa + G)) <= TOL, variant
