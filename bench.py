@@ -69,7 +69,7 @@ def run_single(sph, name, steps, warmup, profile_steps=20):
 def roofline(sph, res):
     """HBM roofline of the dominant kernel: algorithmic bytes per launch / its mean launch duration."""
     kt = res["kernel_ms"]
-    cand = {k: kt[k] for k in ("kick_drift_key", "reorder", "density_eos", "force_kick")}
+    cand = {k: kt[k] for k in ("kick_drift", "density_eos", "force_kick")}
     dom = max(cand, key=cand.get)
     algo = sph.KERNEL_ALGO_BYTES[dom] * res["n_fluid"]
     achieved = algo / (kt[dom] * 1e-3) / 1e9

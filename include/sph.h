@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 1
+#define SPH_ABI_VERSION 2
 
 typedef enum sph_error {
     SPH_OK = 0,
@@ -64,21 +64,25 @@ typedef struct sph_params {
 
 typedef struct sph_ctx sph_ctx;
 
-/* names of the per-step kernels, in launch order (index into sph_kernel_times.ms) */
+/* names of the per-step kernels, in launch order (index into sph_kernel_times.ms).  The kernels marked [R] are
+ * the rebuild of the neighbour structure (the reference's update_neighbors_context :104-124 + find_neighbors
+ * :126-153): they are launched every step and return at once unless kick/drift asked for a rebuild. */
 enum {
-    SPH_K_KICK_DRIFT_KEY = 0,  /* :615-624 + cell index of :111-113 + histogram */
-    SPH_K_SCAN_REDUCE    = 1,  /* counting sort: per-block cell-count sums       */
-    SPH_K_SCAN_APPLY     = 2,  /* counting sort: exclusive scan -> cell_start    */
-    SPH_K_REORDER        = 3,  /* counting sort: scatter to cell-contiguous order (replaces the linked list of :104-124) */
-    SPH_K_DENSITY_EOS    = 4,  /* :263-289 + :294-301                            */
-    SPH_K_FORCE_KICK     = 5,  /* :303-373 + :637-640                            */
-    SPH_K_HALO           = 6,  /* slab mode only: halo pack/ingest               */
-    SPH_K_COUNT          = 7
+    SPH_K_KICK_DRIFT     = 0,  /* :615-624 in place; requests a rebuild when a particle moved > skin/2 since the last */
+    SPH_K_KEY_HIST       = 1,  /* [R] cell index of :111-113 + histogram (counting sort pass 1)      */
+    SPH_K_SCAN           = 2,  /* [R] counting sort: exclusive scan -> cell_start (two launches)     */
+    SPH_K_REORDER        = 3,  /* [R] counting sort: scatter to cell-contiguous order (replaces the linked list of :104-124) */
+    SPH_K_BUILD_LIST     = 4,  /* [R] find_neighbors :126-153 once per rebuild: per-particle neighbour lists */
+    SPH_K_DENSITY_EOS    = 5,  /* :263-289 + :294-301                            */
+    SPH_K_FORCE_KICK     = 6,  /* :303-373 + :637-640                            */
+    SPH_K_HALO           = 7,  /* end-of-step marker (slab mode: halo pack/ingest) */
+    SPH_K_COUNT          = 8
 };
 typedef struct sph_kernel_times {
-    float ms[SPH_K_COUNT];     /* mean device time per launch of each kernel, HIP events on the context's stream */
+    float ms[SPH_K_COUNT];     /* mean device time per step of each kernel, HIP events on the context's stream */
     float step_ms;             /* mean device time of one whole step */
     int   nsteps;
+    int   rebuilds;            /* how many of the nsteps rebuilt the neighbour structure */
 } sph_kernel_times;
 
 /* reference defaults (:11-20), box 4 x 2 */
@@ -119,8 +123,24 @@ int  sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed);
 
 int  sph_n_fluid(const sph_ctx *ctx);
 int  sph_n_boundary(const sph_ctx *ctx);
-/* n_cells (rows, y) and m_cells (columns, x) as :93-94 computes them */
+/* n_cells (rows, y) and m_cells (columns, x) as :93-94 computes them (cell length 2H) */
 int  sph_grid_dims(const sph_ctx *ctx, int *n_cells, int *m_cells);
+/* the device's own neighbour grid: rows, columns and cell length 2H + skin (slab mode: the local grid) */
+int  sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell);
+
+/* ---- neighbour-structure reuse (Verlet skin) ----
+ * The reference rebuilds its linked list every step (:626) and searches it four times per particle (:278, :283,
+ * :314, :343).  Here one rebuild (counting sort + per-particle neighbour lists holding every pair closer than
+ * 2H + skin) serves density and force, and stays in use until a particle has moved more than skin/2 from where it
+ * was at the rebuild — until then no unlisted pair can be inside the support 2H, and listed pairs beyond 2H
+ * contribute exactly 0.  Results do not depend on the skin (beyond summation order).  skin = 0: rebuild every step.
+ * The skin is a fraction of 2H, process-wide, read by sph_create / sph_create_slab (default: $SPH_SKIN or 0). */
+int   sph_set_default_skin(float fraction_of_2h);
+float sph_default_skin(void);
+/* cell length of the device grid for these parameters and the current default skin (what slab hosts must bin with) */
+float sph_device_cell(const sph_params *prm);
+/* rebuilds since creation, and tiles that list builds have put on the direct (no list) path */
+int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
 /* total particles clamped into the domain so far (0 in a healthy run) */
 long long sph_out_of_domain_count(sph_ctx *ctx);
 

@@ -26,9 +26,9 @@ PARTICLE = np.dtype([("x", "<f4"), ("y", "<f4"), ("u", "<f4"), ("v", "<f4"),
 
 SPH_OK, SPH_E_ARG, SPH_E_HIP, SPH_E_OUT_OF_DOMAIN, SPH_E_NAN = 0, -1, -2, -3, -4
 SPH_E_NOMEM, SPH_E_CAPACITY, SPH_E_STATE = -5, -6, -7
-KERNEL_NAMES = ["kick_drift_key", "scan_reduce", "scan_apply", "reorder", "density_eos", "force_kick", "halo"]
-# algorithmic HBM bytes per fluid particle per launch (scan is per cell)
-KERNEL_ALGO_BYTES = {"kick_drift_key": 44.0 + 5.2, "reorder": 44.0, "density_eos": 16.6, "force_kick": 40.0}
+KERNEL_NAMES = ["kick_drift", "key_hist", "scan", "reorder", "build_list", "density_eos", "force_kick", "halo"]
+# algorithmic HBM bytes per fluid particle per launch (P1 44, P2 5.2, P4 44, P5 16.6, P6 40)
+KERNEL_ALGO_BYTES = {"kick_drift": 44.0, "key_hist": 5.2, "reorder": 44.0, "density_eos": 16.6, "force_kick": 40.0}
 STEP_ALGO_BYTES = 152.0
 
 # every symbol include/sph.h and include/sph_host.h declare
@@ -36,7 +36,8 @@ ABI_SYMBOLS = [
     "sph_params_default", "sph_abi_version", "sph_error_string", "sph_device_count",
     "sph_create", "sph_destroy", "sph_last_error", "sph_step", "sph_sync",
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_stats",
-    "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_out_of_domain_count",
+    "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
+    "sph_set_default_skin", "sph_default_skin", "sph_device_cell", "sph_rebuild_stats",
     "sph_upload_state", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
     "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
     "sph_render_metaballs",
@@ -58,7 +59,7 @@ class Params(C.Structure):
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("ms", C.c_float * 7), ("step_ms", C.c_float), ("nsteps", C.c_int)]
+    _fields_ = [("ms", C.c_float * 8), ("step_ms", C.c_float), ("nsteps", C.c_int), ("rebuilds", C.c_int)]
 
 
 class SlabDesc(C.Structure):
@@ -121,6 +122,12 @@ def hip_lib():
         L.sph_grid_dims.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
         L.sph_out_of_domain_count.argtypes = [vp]
         L.sph_out_of_domain_count.restype = C.c_longlong
+        L.sph_device_grid.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(cf)]
+        L.sph_set_default_skin.argtypes = [cf]
+        L.sph_default_skin.restype = cf
+        L.sph_device_cell.argtypes = [C.POINTER(Params)]
+        L.sph_device_cell.restype = cf
+        L.sph_rebuild_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.sph_upload_state.argtypes = [vp, vp]
         L.sph_eval_density.argtypes = [vp]
         L.sph_eval_pressure.argtypes = [vp]
@@ -227,6 +234,17 @@ def dam_break(n_slabs):
     return scene_block((0.0, 1200.0 * n_slabs, 0.0, 60.0), 0.3, 0.3, 4000 * n_slabs, 500)
 
 
+def set_default_skin(fraction_of_2h):
+    """Verlet skin of contexts created from now on, as a fraction of 2H (0 = rebuild the neighbour structure every step)."""
+    rc = hip_lib().sph_set_default_skin(float(fraction_of_2h))
+    if rc:
+        raise SphError(rc, "skin must be within [0, 1]")
+
+
+def default_skin():
+    return float(hip_lib().sph_default_skin())
+
+
 class GravitySource:
     """get_gravity / get_gravity_routine of the reference (:431-464) behind one sample(t) call."""
 
@@ -315,6 +333,18 @@ class Context:
     def out_of_domain(self):
         return int(self.L.sph_out_of_domain_count(self.h))
 
+    def device_grid(self):
+        """rows, cols, cell length of the device's neighbour grid (cell = 2H + skin)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_float()
+        self._chk(self.L.sph_device_grid(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def rebuild_stats(self):
+        """(rebuilds of the neighbour structure since creation, tiles put on the direct path by them)."""
+        a, b = C.c_longlong(), C.c_longlong()
+        self._chk(self.L.sph_rebuild_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def upload_state(self, fluid):
         fluid = np.ascontiguousarray(fluid, PARTICLE)
         assert len(fluid) == self.n
@@ -332,8 +362,9 @@ class Context:
     def profile_steps(self, nsteps, gx=0.0, gy=-9.81):
         kt = KernelTimes()
         self._chk(self.L.sph_profile_steps(self.h, gx, gy, nsteps, C.byref(kt)))
-        d = {KERNEL_NAMES[k]: kt.ms[k] for k in range(6)}
+        d = {KERNEL_NAMES[k]: kt.ms[k] for k in range(7)}
         d["step"] = kt.step_ms
+        d["rebuilds_per_step"] = kt.rebuilds / max(kt.nsteps, 1)
         return d
 
     def time_kernel(self, name, reps=20):
@@ -358,3 +389,11 @@ class Context:
 
 
 from . import slab  # noqa: E402,F401  (host-side slab decomposition: partitioner, transports, runner)
+
+
+def _device_cell(prm):
+    """cell length of the device grid (2H + skin) from the C ABI, so that slab hosts bin exactly like the device."""
+    return float(hip_lib().sph_device_cell(C.byref(prm)))
+
+
+slab.set_cell_fn(_device_cell)

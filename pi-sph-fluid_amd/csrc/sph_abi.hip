@@ -32,6 +32,7 @@ struct sph_ctx {
     size_t halo_bytes = 0;
     uint32_t *d_ids = nullptr;  // slab read-back staging
     int variant = 0;
+    float skin = 0.0f;          // absolute skin [m] of this context's neighbour lists
     sph_particle *d_aos = nullptr;    // n  : read-back / upload staging, original order
     sph_particle *d_baos = nullptr;   // nb
     float *d_du = nullptr, *d_dv = nullptr;
@@ -49,6 +50,17 @@ struct sph_ctx {
 };
 
 namespace {
+
+// process-wide default skin as a fraction of 2H (sph_set_default_skin / $SPH_SKIN); < 0 = not set yet
+float g_skin_frac = -1.0f;
+float default_skin_frac() {
+    if (g_skin_frac < 0.0f) {
+        const char *e = getenv("SPH_SKIN");
+        const float v = e ? (float)atof(e) : 0.0f;
+        g_skin_frac = (v >= 0.0f && v <= 1.0f) ? v : 0.0f;
+    }
+    return g_skin_frac;
+}
 
 int fail(sph_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
     if (ctx) {
@@ -79,7 +91,7 @@ int dalloc(sph_ctx *ctx, T **p, size_t count) {
 }
 
 // derived constants, evaluated like the reference's macros (double where its expression is double)
-int make_consts(const sph_params &p, Consts &c) {
+int make_consts(const sph_params &p, float skin_frac, Consts &c) {
     if (!(p.h > 0) || !(p.r > 0) || !(p.rho0 > 0) || !(p.c > 0) || !(p.dt > 0) || !(p.vol > 0)) return SPH_E_ARG;
     if (!(p.x_max > p.x_min) || !(p.y_max > p.y_min)) return SPH_E_ARG;
     const double H = p.h;
@@ -88,6 +100,10 @@ int make_consts(const sph_params &p, Consts &c) {
     c.inv_h = 1.0f / p.h;
     const float two_h = 2 * p.h;                                         // :144
     c.cut2 = two_h * two_h;
+    const float skin = skin_frac * two_h;
+    c.cut_list2 = (two_h + skin) * (two_h + skin);
+    c.lim2 = (0.5f * skin) * (0.5f * skin);
+    if (skin > 0.0f) c.lim2 *= 0.999f;      // rounding of the squared distances stays on the safe side
     c.nf = (float)nf;
     c.grad_c = (float)(5.0 * nf / (H * H));                              // :56-59
     const double q = p.k2;                                               // W(0.2 H): q = 0.2   :325
@@ -104,7 +120,7 @@ int make_consts(const sph_params &p, Consts &c) {
     c.half_dt = (float)(0.5 * (double)p.dt);                             // :616
     c.x_min = p.x_min;
     c.y_min = p.y_min;
-    c.cell = 2 * p.h;                                                    // :596
+    c.cell = two_h + skin;                                               // :596 (2H) + skin
     c.inv_cell = 1.0f / c.cell;
     double rows = (double)(int)((p.y_max - p.y_min) / c.cell) + 1;       // :93
     double cols = (double)(int)((p.x_max - p.x_min) / c.cell) + 1;       // :94
@@ -125,15 +141,19 @@ size_t padded_items(const Consts &c) {
     return (n_items + SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
 }
 
-// the six launches of one time step (SPH_K_* order); ev != nullptr records an event before each
+// the launches of one time step (SPH_K_* order); ev != nullptr records an event before each
 void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
-    if (ev) (void)hipEventRecord(ev[SPH_K_KICK_DRIFT_KEY], st);
-    launch_kick_drift_key(st, ctx->c, ctx->a, ctx->cap);
-    if (ev) (void)hipEventRecord(ev[SPH_K_SCAN_REDUCE], st);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ev ? ev[SPH_K_SCAN_APPLY] : nullptr);
+    if (ev) (void)hipEventRecord(ev[SPH_K_KICK_DRIFT], st);
+    launch_kick_drift(st, ctx->c, ctx->a, ctx->cap);
+    if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
+    launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);       // the rebuild kernels: no-ops unless requested
+    if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.flags);
     if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+    if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
+    launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
     if (ev) (void)hipEventRecord(ev[SPH_K_FORCE_KICK], st);
@@ -157,9 +177,10 @@ int enqueue_slab_half(sph_ctx *ctx, int half) {
         for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, HALO_HDR * sizeof(uint32_t), st));
         launch_kick_drift_key(st, ctx->c, ctx->a, ctx->cap);
     } else {
-        launch_ingest(st, ctx->c, ctx->a, ctx->cap);
-        launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, nullptr);
+        launch_ingest(st, ctx->c, ctx->a, ctx->cap);      // also requests the rebuild below (every step in slab mode)
+        launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.flags);
         launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+        launch_build_list(st, ctx->c, ctx->a, ctx->cap);
         launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
         launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
     }
@@ -215,12 +236,15 @@ bool ensure_graph(sph_ctx *ctx) {
     return true;
 }
 
-// bin the current (pos, velt, id) state: keys + histogram, scan, scatter; then velt := sorted vel
+// rebuild from the current (pos, velt, id) state: keys + histogram, scan, scatter, neighbour lists; then velt := sorted vel
 int resort_state(sph_ctx *ctx) {
     hipStream_t st = ctx->stream;
-    launch_key_only(st, ctx->c, ctx->a, ctx->cap);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, nullptr);
+    launch_set_rebuild(st, ctx->a, true);
+    launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.velt);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.flags);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+    launch_build_list(st, ctx->c, ctx->a, ctx->cap);
+    launch_set_rebuild(st, ctx->a, false);
     HIPCHK(ctx, hipMemcpyAsync(ctx->a.velt, ctx->a.vel, sizeof(float2) * (size_t)ctx->cap, hipMemcpyDeviceToDevice, st));
     return SPH_OK;
 }
@@ -300,7 +324,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
                  const sph_particle *boundary, int n_boundary, bool psi_given, float gx, float gy, int device,
                  const SlabSpec *slab) {
     ctx->prm = *prm;
-    if (make_consts(*prm, ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "invalid parameters or grid too large");
+    if (make_consts(*prm, default_skin_frac(), ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "invalid parameters or grid too large");
+    ctx->skin = ctx->c.cell - 2 * prm->h;
     if (slab) {
         Consts &c = ctx->c;
         const int G = 2;
@@ -338,8 +363,10 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     const size_t tiles = pad / SCAN_TILE;
 #define ALLOC(ptr, cnt) if ((rc = dalloc(ctx, &(ptr), (cnt))) != SPH_OK) return rc
     ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
-    ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.hitmask, 3 * n); ALLOC(a.skey, n);
-    ALLOC(a.tiles, 11 * ((n + 255) / 256 + 9)); ALLOC(a.slot, n > nb ? n : nb);
+    ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.skey, n); ALLOC(a.pos_ref, n);
+    const size_t ntiles = (n + 255) / 256 + 9;
+    ALLOC(a.tiles, TILE_WORDS * ntiles); ALLOC(a.nlist, (size_t)LIST_WORDS_PER_TILE * ntiles);
+    ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
@@ -374,8 +401,9 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     std::vector<float> hpsi(nb ? nb : 1);
     for (size_t i = 0; i < nb; i++) { hb[i] = make_float2(boundary[i].x, boundary[i].y); hpsi[i] = boundary[i].m; }
     HIPCHK(ctx, hipMemcpyAsync(bpos_in, hb.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
+    launch_set_rebuild(st, a, true);        // the scan is a rebuild kernel
     launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.dirty, a.flags, n_boundary);
-    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, nullptr);
+    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.flags);
     launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary);
     if (psi_given) {
         // psi was computed on the full wall set (a slab sees only its part of the walls): scatter it to bin order
@@ -439,7 +467,7 @@ int sph_create_slab(sph_ctx **out, const sph_params *prm, const sph_slab_desc *d
         sph_destroy(tmp);
     }
     Consts cg;
-    if (make_consts(*prm, cg) != SPH_OK) return fail(ctx, SPH_E_ARG, "sph_create_slab: invalid parameters");
+    if (make_consts(*prm, default_skin_frac(), cg) != SPH_OK) return fail(ctx, SPH_E_ARG, "sph_create_slab: invalid parameters");
     const int lo = desc->col_begin - 2, hi = desc->col_end + 2;   // local columns [lo, hi)
     std::vector<sph_particle> bloc;
     for (int i = 0; i < n_boundary_all; i++) {
@@ -528,8 +556,38 @@ int sph_n_fluid(const sph_ctx *ctx) { return ctx ? ctx->n : SPH_E_ARG; }
 int sph_n_boundary(const sph_ctx *ctx) { return ctx ? ctx->nb : SPH_E_ARG; }
 int sph_grid_dims(const sph_ctx *ctx, int *n_cells, int *m_cells) {
     if (!ctx) return SPH_E_ARG;
-    if (n_cells) *n_cells = ctx->c.rows;
-    if (m_cells) *m_cells = ctx->c.cols;
+    const sph_params &p = ctx->prm;
+    const float cell = 2 * p.h;                                                        // :596
+    if (n_cells) *n_cells = (int)((p.y_max - p.y_min) / cell) + 1;                     // :93
+    if (m_cells) *m_cells = (int)((p.x_max - p.x_min) / cell) + 1;                     // :94
+    return SPH_OK;
+}
+int sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell) {
+    if (!ctx) return SPH_E_ARG;
+    if (rows) *rows = ctx->c.rows;
+    if (cols) *cols = ctx->c.cols;
+    if (cell) *cell = ctx->c.cell;
+    return SPH_OK;
+}
+int sph_set_default_skin(float fraction_of_2h) {
+    if (!(fraction_of_2h >= 0.0f && fraction_of_2h <= 1.0f)) return SPH_E_ARG;
+    g_skin_frac = fraction_of_2h;
+    return SPH_OK;
+}
+float sph_default_skin(void) { return default_skin_frac(); }
+float sph_device_cell(const sph_params *prm) {
+    if (!prm) return 0.0f;
+    const float two_h = 2 * prm->h;
+    return two_h + default_skin_frac() * two_h;
+}
+int sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    uint32_t h[FLAG_COUNT] = {0};
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (rebuilds) *rebuilds = h[FLAG_NREBUILD];
+    if (direct_tiles) *direct_tiles = h[FLAG_DIRECT_TILES];
     return SPH_OK;
 }
 long long sph_out_of_domain_count(sph_ctx *ctx) {
@@ -544,8 +602,7 @@ int sph_set_variant(sph_ctx *ctx, int variant) {
     if (variant != ctx->variant) {
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         drop_graph(ctx);
-        ctx->variant = variant;
-        if (ctx->stream) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_MASKS_ONLY, ctx->variant);
+        ctx->variant = variant;      // both variants work from the same sorted state
     }
     return SPH_OK;
 }
@@ -577,7 +634,6 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     int rc = resort_state(ctx);
     if (rc) return rc;
     launch_gather_rho_p(st, ctx->c, ctx->a, ctx->n, ctx->d_aos);
-    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_MASKS_ONLY, ctx->variant);   // neighbour masks of the new order
     HIPCHK(ctx, hipGetLastError());
     return check_flags(ctx);
 }
@@ -614,6 +670,9 @@ int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_t
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_profile_steps is single-GPU only");
     (void)hipSetDevice(ctx->device);
     memset(out, 0, sizeof *out);
+    long long r0 = 0, r1 = 0;
+    int rc = sph_rebuild_stats(ctx, &r0, nullptr);
+    if (rc) return rc;
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     double acc[SPH_K_COUNT] = {0}, total = 0;
     for (int s = 0; s < nsteps; s++) {
@@ -631,6 +690,9 @@ int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_t
     for (int k = 0; k < SPH_K_HALO; k++) out->ms[k] = (float)(acc[k] / nsteps);
     out->step_ms = (float)(total / nsteps);
     out->nsteps = nsteps;
+    rc = sph_rebuild_stats(ctx, &r1, nullptr);
+    if (rc) return rc;
+    out->rebuilds = (int)(r1 - r0);
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }

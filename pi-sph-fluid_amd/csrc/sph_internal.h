@@ -15,6 +15,8 @@ struct Consts {
     // kernel maths (pi_sph_fluid.c:45-62)
     float h, inv_h;          // H, 1/H
     float cut2;              // (2H)^2 : support test of :144 on squared distance
+    float cut_list2;         // (2H + skin)^2 : a pair enters a neighbour list below this distance (at rebuild time)
+    float lim2;              // (skin/2)^2 : a particle further than this from its rebuild position forces a rebuild
     float nf;                // 7/(4 pi H^2)          :46
     float grad_c;            // 5 nf / H^2 : -dW/dq / (d H) = grad_c * (1-q/2)^3   (:56-59 with q/d = 1/H)
     float inv_w_k2h;         // 1 / W(0.2 H)          :325
@@ -31,7 +33,7 @@ struct Consts {
     // cell = col * rows + row, so that a column of cells (fixed x range) is one contiguous
     // range of the sorted arrays (3 contiguous candidate ranges per particle; slab halos are
     // contiguous).  The reference is row-major (:113); the pair sets are identical.
-    float x_min, y_min, cell; // cell length 2H :596
+    float x_min, y_min, cell; // cell length 2H :596, plus the skin
     float inv_cell;           // 1/cell: the device bins with a multiply (see cell_of)
     int rows, cols;          // n_cells (y), m_cells (x) :93-94 — in slab mode: the LOCAL column count (owned + 2*ghost)
     int n_cells;             // rows * cols
@@ -53,11 +55,12 @@ struct Arrays {
     float *prs;        // p
     float2 *acc;       // du_dt, dv_dt
     uint32_t *skey;    // sorted cell keys
-    uint32_t *tiles;   // one 44-byte TileInfo record per 256-particle workgroup (sph_tiled.inc)
-    uint32_t *hitmask; // 3 x n: per particle, per candidate segment, bit k = candidate k is a neighbour (density -> force)
+    float2 *pos_ref;   // x,y at the last rebuild (the positions the neighbour lists were built from)
+    uint32_t *tiles;   // one TILE_WORDS-word TileInfo record per 256-particle workgroup (sph_list.inc)
+    uint32_t *nlist;   // neighbour lists: per tile LROWS2 rows x 256 lanes of 2 x 16-bit entries (sph_list.inc)
     // staging (T)
     float4 *pk;        // x, y, id bits, cell key bits (after kick/drift, before the sort)
-    float2 *velt;      // u,v after the second half kick, sorted order: the velocity between steps
+    float2 *velt;      // u,v after the second half kick, sorted order: the velocity between steps (vel: after the first)
     float2 *velk;      // u,v after the first half kick, staging order (source of the sort)
     uint32_t *slot;    // arrival rank of the particle inside its cell
     // grid
@@ -72,13 +75,26 @@ struct Arrays {
     uint32_t *bcell_start; // n_cells + 1
     // misc
     float2 *grav;       // gravity vector read by the force kernel
-    uint32_t *flags;    // [0] out-of-domain count, [1] NaN count, [2] max rho bits, [3] max speed bits, [4] capacity overflow
+    uint32_t *flags;    // see FLAG_*
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
     // slab halo buffers: uint32 header[4] = {count,..} + halo_cap records of 5 words (x, y, u, v, id)
     uint32_t *send[2], *recv[2];   // [0] = left neighbour, [1] = right neighbour
 };
 
-enum { FLAG_OOB = 0, FLAG_NAN = 1, FLAG_MAXRHO = 2, FLAG_MAXSPEED = 3, FLAG_CAPACITY = 4, FLAG_COUNT = 8 };
+enum {
+    FLAG_OOB = 0,           // particles clamped into edge cells (count)
+    FLAG_NAN = 1,           // NaN/Inf positions (count)
+    FLAG_MAXRHO = 2,        // sph_stats: max rho bits
+    FLAG_MAXSPEED = 3,      // sph_stats: max speed bits
+    FLAG_CAPACITY = 4,      // slab mode: capacity overflow (count)
+    FLAG_REBUILD = 5,       // set by kick/drift (or the host): the rebuild kernels of this step run; cleared by density
+    FLAG_NREBUILD = 6,      // rebuilds so far
+    FLAG_DIRECT_TILES = 7,  // tiles put on the direct path by list builds so far
+    FLAG_COUNT = 8
+};
+constexpr int TILE_WORDS = 16;           // 32-bit words per tile record
+constexpr int LIST_WORDS_PER_TILE = 24 * 256;   // LROWS2 x BLK (sph_list.inc static_asserts this)
+constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle list padding points at (finite: no NaN)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record
 
@@ -90,23 +106,27 @@ constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;   // 2048 cells per block
 void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy);
 // In every per-step launcher `cap` is the launch capacity (grid size, array stride); the live particle count is
 // read on the device from a.dn[0], so slab mode (count changes every step) and single mode share the kernels.
-// first half kick + drift + cell key + histogram (:615-624, :111-113); in slab mode also packs the halo buffers
+// set / clear flags[FLAG_REBUILD] from the host side of the stream
+void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
+// single-GPU step: first half kick + drift in place (:615-624); requests a rebuild when the lists may be stale
+void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// slab mode: first half kick + drift + cell key + histogram into the staging arrays + halo pack
 void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int cap);
-// keys + histogram only, state taken as is (init and sph_upload_state)
-void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// rebuild: keys + histogram of (pos, vsrc, id) as they are, into the staging arrays
+void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc);
 // slab mode: append the received halo records to the staging arrays, then dn[0] = owned + received
 void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap);
 // slab mode: owned particles (sorted order) -> compact AoS + ids; count left in dn[1]... see sph_abi.hip
 void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int cap, sph_particle *out_dev, uint32_t *ids_dev,
                          float *du, float *dv);
+// rebuild kernels (no-ops unless flags[FLAG_REBUILD]): scan, scatter, tile records + neighbour lists
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
-                 uint32_t *block_sums, hipEvent_t mid /* optional: recorded between the two scan kernels */);
+                 uint32_t *block_sums, const uint32_t *flags);
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap);
-// variant: 0 = LDS-tiled (default), 1 = direct global loads
-// mode: what the density pass writes.  The tiled force kernel consumes the neighbour masks the tiled
-// density kernel wrote for the SAME sorted order, so every re-sort must be followed by a density launch
-// (any mode) before a force launch.
-enum { DENS_RHO = 0, DENS_RHO_EOS = 1, DENS_MASKS_ONLY = 2 };
+void launch_build_list(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// variant: 0 = LDS-tiled neighbour lists (default), 1 = direct global loads over the cell ranges (A/B measurements)
+// mode: what the density pass writes
+enum { DENS_RHO = 0, DENS_RHO_EOS = 1 };
 void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant);
 void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool from_prs);
 void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool kick, int variant);

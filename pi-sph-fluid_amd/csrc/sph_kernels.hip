@@ -1,17 +1,22 @@
 // sph_kernels.hip — hand-written gfx950 kernels of the 2-D WCSPH step.
 //
 // What each kernel restates (file = /root/reference/pi_sph_fluid.c):
-//   k_kick_drift_key   kick 1/2 + drift :615-624, cell index :111-113, histogram (counting sort pass 1)
+//   k_kick_drift       kick 1/2 + drift :615-624, in place; asks for a neighbour-structure rebuild when a particle
+//                      has moved more than half the skin since the last one
+//   k_kick_drift_key   cell index :111-113 + histogram (counting sort pass 1); slab mode: with kick 1/2 + drift
 //   k_scan_*           exclusive scan of the cell histogram (counting sort pass 2)
 //   k_reorder          scatter into cell-contiguous order (replaces the linked list :104-124)
+//   k_build_list       find_neighbors :126-153 once per rebuild: per-particle neighbour lists (sph_list.inc)
 //   k_density_*        calculate_density :263-289 (+ calculate_particle_pressure :294-301 when fused)
 //   k_force_*          calculate_accelerations :303-373 (+ kick 1/2 :637-640 when fused)
 //   k_boundary_psi     calculate_boundary_pseudomass :242-261
 //
-// Data layout: SoA, cell-sorted every step.  Cells are linearised column-major
-// (cell = col*rows + row), so the 3x3 neighbourhood of a particle is THREE contiguous ranges
-// of the sorted arrays (one per column: rows r-1..r+1).  No MFMA anywhere: there is no dense
-// contraction in this workload; the kernels are HBM/LDS/VALU work.
+// Data layout: SoA, cell-sorted at every rebuild of the neighbour structure (the reference rebuilds its
+// linked list every step, :626; here a rebuild happens when the lists could have gone stale — every step with
+// skin = 0).  Cells are linearised column-major (cell = col*rows + row), so the 3x3 neighbourhood of a particle is
+// THREE contiguous ranges of the sorted arrays (one per column: rows r-1..r+1).  The kernels marked "rebuild" start
+// with `if (!flags[FLAG_REBUILD]) return;` so that one captured graph serves every step.  No MFMA anywhere: there
+// is no dense contraction in this workload; the kernels are HBM/LDS/VALU work.
 #include <cstdlib>
 
 #include "sph_internal.h"
@@ -40,6 +45,13 @@ DEV void cell_of(const Consts &c, float x, float y, int &row, int &col, bool &oo
     col = min(max(col, 0), c.cols - 1);
 }
 
+// cell (row, col) of a sorted particle from its key (cells are column-major).  Used where the CURRENT position must
+// not be used: between rebuilds a particle may have left the cell it is sorted under.
+DEV void cell_of_key(const Consts &c, uint32_t key, int &row, int &col) {
+    col = (int)(key / (uint32_t)c.rows);
+    row = (int)(key - (uint32_t)col * (uint32_t)c.rows);
+}
+
 // Wendland C2 without its normalising factor: (1 - q/2)^4 (1 + 2q), q = d/H   (:45-50)
 DEV float w_shape(const Consts &c, float d2) {
     float d = __builtin_amdgcn_sqrtf(d2);
@@ -58,10 +70,47 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy) {
     hipLaunchKernelGGL(k_set_gravity, dim3(1), dim3(1), 0, st, a.grav, gx, gy);
 }
 
+__global__ void k_set_flag(uint32_t *flags, int which, uint32_t value) { flags[which] = value; }
+void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, st, a.flags, (int)FLAG_REBUILD, on ? 1u : 0u);
+}
+
 // ------------------------------------------------------------------------------------------
-// P1: kick 1/2 + drift + key + histogram.  44 B/particle + 4 B slot.
-// INTEGRATE: read the OWNED range of the sorted arrays (cell_start of the previous sort; single GPU: everything),
-// integrate, write staging entries 0..n_own-1.  !INTEGRATE: take entries 0..dn[0]-1 as they are (init / upload).
+// kick 1/2 + drift in place (:615-624), 48 B/particle.  The neighbour lists were built at pos_ref with a skin:
+// they hold every pair that can come within 2H while no particle has moved more than skin/2 from its pos_ref.
+// The first particle beyond that (or any motion at all with skin = 0, or a NaN) requests a rebuild, which the
+// rebuild kernels queued behind this one carry out in the same step.
+__global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict__ pos, const float2 *__restrict__ pos_ref,
+                                                    const float2 *__restrict__ acc, const float2 *__restrict__ velt,
+                                                    float2 *__restrict__ vel, uint32_t *__restrict__ flags,
+                                                    const uint32_t *__restrict__ dn) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= (int)dn[0]) return;
+    const float2 a = acc[i], r = pos_ref[i];
+    float2 v = velt[i], p = pos[i];
+    v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
+    v.y = fmaf(c.half_dt, a.y, v.y);
+    p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
+    p.y = fmaf(c.dt, v.y, p.y);
+    pos[i] = p;
+    vel[i] = v;
+    const float dx = p.x - r.x, dy = p.y - r.y;
+    const bool moved = !(fmaf(dx, dx, dy * dy) <= c.lim2);      // true for NaN too
+    if (__ballot(moved) != 0ull && (threadIdx.x & 63) == (int)__builtin_ctzll(__ballot(1)))
+        flags[FLAG_REBUILD] = 1u;
+}
+
+void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+    if (cap <= 0) return;
+    hipLaunchKernelGGL(k_kick_drift, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel,
+                       a.flags, a.dn);
+}
+
+// ------------------------------------------------------------------------------------------
+// P1: key + histogram into the staging arrays (rebuild kernel).  44 B/particle + 4 B slot.
+// !INTEGRATE (single GPU, init, upload): take entries 0..dn[0]-1 of (pos, vsrc, id) as they are.
+// INTEGRATE (slab mode): read the OWNED range of the sorted arrays (cell_start of the previous sort), kick 1/2 +
+// drift (:615-624), write staging entries 0..n_own-1.
 // SLAB: also append every particle now inside a neighbour's reach (its two outermost owned columns, plus the
 // column it may just have migrated into) to that neighbour's halo buffer: ONE exchange per step carries both the
 // ghosts and the ownership migration.
@@ -80,12 +129,13 @@ DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, ui
 template <bool INTEGRATE, bool SLAB>
 __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *__restrict__ pos,
                                                         const uint32_t *__restrict__ id, const float2 *__restrict__ acc,
-                                                        const float2 *__restrict__ velt, const uint32_t *__restrict__ cs,
+                                                        const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs,
                                                         float2 *__restrict__ velk, float4 *__restrict__ pk,
                                                         uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
                                                         uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
                                                         uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
                                                         uint32_t *__restrict__ send_r) {
+    if (!INTEGRATE && flags[FLAG_REBUILD] == 0u) return;      // rebuild kernel
     const int t = blockIdx.x * BLK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int src0 = 0, n;
@@ -104,7 +154,7 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
     if (active) {
         const int i = src0 + t;
         p = pos[i];
-        v = velt[i];
+        v = vsrc[i];
         pid = id[i];
         if (INTEGRATE) {
             float2 a = acc[i];
@@ -149,16 +199,16 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
     }
 }
 
-#define KDK_ARGS c, a.pos, a.id, a.acc, a.velt, a.cell_start, a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.dn, a.send[0], a.send[1]
+#define KDK_ARGS(vsrc) c, a.pos, a.id, a.acc, vsrc, a.cell_start, a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.dn, a.send[0], a.send[1]
 void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     if (cap <= 0) return;
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
-    if (c.has_left || c.has_right) hipLaunchKernelGGL((k_kick_drift_key<true, true>), g, b, 0, st, KDK_ARGS);
-    else hipLaunchKernelGGL((k_kick_drift_key<true, false>), g, b, 0, st, KDK_ARGS);
+    if (c.has_left || c.has_right) hipLaunchKernelGGL((k_kick_drift_key<true, true>), g, b, 0, st, KDK_ARGS(a.velt));
+    else hipLaunchKernelGGL((k_kick_drift_key<true, false>), g, b, 0, st, KDK_ARGS(a.velt));
 }
-void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc) {
     if (cap <= 0) return;
-    hipLaunchKernelGGL((k_kick_drift_key<false, false>), dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, KDK_ARGS);
+    hipLaunchKernelGGL((k_kick_drift_key<false, false>), dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, KDK_ARGS(vsrc));
 }
 #undef KDK_ARGS
 
@@ -178,6 +228,7 @@ __global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__rest
         if ((c.has_left && (int)recv_l[0] > c.halo_cap) || (c.has_right && (int)recv_r[0] > c.halo_cap))
             atomicAdd(&flags[FLAG_CAPACITY], 1u);
         dn[0] = (uint32_t)total;
+        flags[FLAG_REBUILD] = 1u;      // slab mode re-sorts and re-lists every step (the local particle set changes)
     }
     if (t >= nl + nr) return;
     const int dst = n_own + t;
@@ -227,8 +278,10 @@ DEV uint32_t block_sum_256(uint32_t v, uint32_t *lds4) {
 
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__restrict__ count,
                                                             const uint32_t *__restrict__ dirty,
-                                                            uint32_t *__restrict__ block_sums) {
+                                                            uint32_t *__restrict__ block_sums,
+                                                            const uint32_t *__restrict__ flags) {
     __shared__ uint32_t red[4];
+    if (flags[FLAG_REBUILD] == 0u) return;      // rebuild kernel
     if (dirty[blockIdx.x] == 0u) {      // untouched since it was last zeroed: all counts are 0
         if (threadIdx.x == 0) block_sums[blockIdx.x] = 0u;
         return;
@@ -243,9 +296,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__re
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict__ count,
                                                            const uint32_t *__restrict__ block_sums,
                                                            uint32_t *__restrict__ dirty,
-                                                           uint32_t *__restrict__ cell_start, int n_items) {
+                                                           uint32_t *__restrict__ cell_start, int n_items,
+                                                           const uint32_t *__restrict__ flags) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t wave_tot[4];
+    if (flags[FLAG_REBUILD] == 0u) return;      // rebuild kernel
     // offset of this tile = sum of the tiles before it (<= a few thousand L2-resident words)
     uint32_t off = 0;
     for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_BLOCK) off += block_sums[k];
@@ -298,39 +353,39 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
 }
 
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
-                 uint32_t *block_sums, hipEvent_t mid) {
+                 uint32_t *block_sums, const uint32_t *flags) {
     int n_items = c.n_cells + 1;
     int tiles = (n_items + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, dirty, block_sums);
-    if (mid) (void)hipEventRecord(mid, st);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums, dirty, cell_start, n_items);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, dirty, block_sums, flags);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums, dirty, cell_start, n_items, flags);
 }
 
 // ------------------------------------------------------------------------------------------
-// P4: scatter to cell order.
+// P4: scatter to cell order (rebuild kernel).  The sorted positions are the reference positions of the new lists.
 __global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, const float2 *__restrict__ velk,
                                                  const uint32_t *__restrict__ slot,
                                                  const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
-                                                 float2 *__restrict__ vel, uint32_t *__restrict__ id,
-                                                 uint32_t *__restrict__ skey, const uint32_t *__restrict__ dn) {
+                                                 float2 *__restrict__ pos_ref, float2 *__restrict__ vel,
+                                                 uint32_t *__restrict__ id, uint32_t *__restrict__ skey,
+                                                 const uint32_t *__restrict__ dn, const uint32_t *__restrict__ flags) {
+    if (flags[FLAG_REBUILD] == 0u) return;
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= (int)dn[0]) return;
     float4 q = pk[i];
     const uint32_t key = __float_as_uint(q.w);
     uint32_t dst = cell_start[key] + slot[i];
     pos[dst] = make_float2(q.x, q.y);
+    pos_ref[dst] = make_float2(q.x, q.y);
     vel[dst] = velk[i];
     id[dst] = __float_as_uint(q.z);
-    skey[dst] = key;        // sorted keys: the tile table of the tiled kernels is built from them
+    skey[dst] = key;        // sorted keys: tile records, and the sort cell of a particle between rebuilds
 }
 
-void launch_tile_table(hipStream_t st, const Consts &c, const Arrays &a, int cap);   // sph_tiled.inc
-
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+    (void)c;
     if (cap <= 0) return;
     hipLaunchKernelGGL(k_reorder, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, a.pk, a.velk, a.slot, a.cell_start, a.pos,
-                       a.vel, a.id, a.skey, a.dn);
-    launch_tile_table(st, c, a, cap);
+                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.flags);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -344,20 +399,22 @@ DEV void eos(const Consts &c, float rho, float &p, float &p_over_rho2) {
 }
 
 // ------------------------------------------------------------------------------------------
-// P5 (variant 1, "direct"): one thread per particle, neighbours read straight from the sorted
-// arrays through L1/L2.
+// P5 (variant 1, "direct": A/B measurements): one thread per particle, the 3x3 cell ranges of its sort cell read
+// straight from the sorted arrays through L1/L2, exact support test on the current positions (valid between
+// rebuilds: the sort cells are 2H + skin wide and nobody is further than skin/2 from where it was sorted).
 template <bool EOS>
 __global__ __launch_bounds__(BLK) void k_density_direct(Consts c, const float2 *__restrict__ pos,
+                                                        const uint32_t *__restrict__ skey,
                                                         const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
                                                         const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
                                                         float2 *__restrict__ rp, float *__restrict__ prs,
-                                                        const uint32_t *__restrict__ dn) {
+                                                        uint32_t *__restrict__ flags, const uint32_t *__restrict__ dn) {
     int i = blockIdx.x * BLK + threadIdx.x;
+    if (i == 0) flags[FLAG_REBUILD] = 0u;       // a rebuild request has been served by the kernels before this one
     if (i >= (int)dn[0]) return;
     float2 pi = pos[i];
     int row, col;
-    bool oob, bad;
-    cell_of(c, pi.x, pi.y, row, col, oob, bad);
+    cell_of_key(c, skey[i], row, col);
     int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
     float sf = 0.0f, sb = 0.0f;
     for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
@@ -437,6 +494,7 @@ DEV float pair_coef(const Consts &c, float d2, float xv, float pr_sum, float rho
 template <bool KICK>
 __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__restrict__ pos,
                                                       const float2 *__restrict__ vel, const float2 *__restrict__ rp,
+                                                      const uint32_t *__restrict__ skey,
                                                       const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
                                                       const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
                                                       const float2 *__restrict__ grav, float2 *__restrict__ acc,
@@ -445,8 +503,7 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
     if (i >= (int)dn[0]) return;
     float2 pi = pos[i], vi = vel[i], rpi = rp[i];
     int row, col;
-    bool oob, bad;
-    cell_of(c, pi.x, pi.y, row, col, oob, bad);
+    cell_of_key(c, skey[i], row, col);
     int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
     float fx = 0.0f, fy = 0.0f, bx = 0.0f, by = 0.0f;
     for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
@@ -487,32 +544,31 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
 
 }  // namespace sph
 
-#include "sph_tiled.inc"
+#include "sph_list.inc"
 
 namespace sph {
 
 void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant) {
     if (cap <= 0) return;
-    if (variant == 0) { launch_density_tiled(st, c, a, cap, mode); return; }
-    if (mode == DENS_MASKS_ONLY) return;      // the direct variant has no masks
+    if (variant == 0) { launch_density_list(st, c, a, cap, mode); return; }
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
     if (mode == DENS_RHO_EOS)
-        hipLaunchKernelGGL(k_density_direct<true>, g, b, 0, st, c, a.pos, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, a.dn);
+        hipLaunchKernelGGL(k_density_direct<true>, g, b, 0, st, c, a.pos, a.skey, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
+                           a.rp, a.prs, a.flags, a.dn);
     else
-        hipLaunchKernelGGL(k_density_direct<false>, g, b, 0, st, c, a.pos, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, a.dn);
+        hipLaunchKernelGGL(k_density_direct<false>, g, b, 0, st, c, a.pos, a.skey, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
+                           a.rp, a.prs, a.flags, a.dn);
 }
 
 void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool kick, int variant) {
     if (cap <= 0) return;
-    if (variant == 0) { launch_force_tiled(st, c, a, cap, kick); return; }
+    if (variant == 0) { launch_force_list(st, c, a, cap, kick); return; }
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
     if (kick)
-        hipLaunchKernelGGL(k_force_direct<true>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.cell_start, a.bpos, a.bpsi,
+        hipLaunchKernelGGL(k_force_direct<true>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.skey, a.cell_start, a.bpos, a.bpsi,
                            a.bcell_start, a.grav, a.acc, a.velt, a.dn);
     else
-        hipLaunchKernelGGL(k_force_direct<false>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.cell_start, a.bpos, a.bpsi,
+        hipLaunchKernelGGL(k_force_direct<false>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.skey, a.cell_start, a.bpos, a.bpsi,
                            a.bcell_start, a.grav, a.acc, a.velt, a.dn);
 }
 

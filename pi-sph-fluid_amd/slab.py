@@ -24,21 +24,33 @@ HALO_REC = 5
 GHOST = 2
 
 
+_cell_fn = None
+
+
+def set_cell_fn(fn):
+    """fn(prm) -> cell length of the device grid (2H + skin); the package sets this to the C ABI's sph_device_cell."""
+    global _cell_fn
+    _cell_fn = fn
+
+
+def device_cell(prm):
+    if _cell_fn is not None:
+        return np.float32(_cell_fn(prm))
+    return np.float32(2) * np.float32(prm.h)
+
+
 def global_columns(prm, x):
     """global cell column of positions x — the device's arithmetic (cell_of): (int)((x - x_min) * (1/cell)), f32."""
-    cell = np.float32(2) * np.float32(prm.h)
-    inv = np.float32(1.0) / cell
+    inv = np.float32(1.0) / device_cell(prm)
     return ((np.asarray(x, np.float32) - np.float32(prm.x_min)) * inv).astype(np.int64)
 
 
 def grid_columns(prm):
-    cell = np.float32(2) * np.float32(prm.h)
-    return int((np.float32(prm.x_max) - np.float32(prm.x_min)) / cell) + 1
+    return int((np.float32(prm.x_max) - np.float32(prm.x_min)) / device_cell(prm)) + 1
 
 
 def grid_rows(prm):
-    cell = np.float32(2) * np.float32(prm.h)
-    return int((np.float32(prm.y_max) - np.float32(prm.y_min)) / cell) + 1
+    return int((np.float32(prm.y_max) - np.float32(prm.y_min)) / device_cell(prm)) + 1
 
 
 def partition_columns(prm, fluid, world, slack=64):
