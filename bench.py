@@ -57,10 +57,12 @@ def run_single(sph, name, steps, warmup, profile_steps=20):
     kt["force_kick"] = ctx.time_kernel("force_kick", 50)
     max_rho, max_speed = ctx.stats()
     rows, cols = ctx.grid_dims()
+    rebuilds, direct_tiles = ctx.rebuild_stats()
     res = {"workload": name, "n_fluid": n, "n_boundary": len(b), "grid_cells": rows * cols,
            "steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
            "mparticle_steps_per_s": steps / dt * n / 1e6, "kernel_ms": kt,
-           "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s,
+           "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s, "skin_frac": sph.default_skin(),
+           "rebuilds": rebuilds, "direct_tiles": direct_tiles,
            "device_mb": ctx.device_bytes() / 1e6}
     ctx.close()
     return res

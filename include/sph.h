@@ -134,7 +134,7 @@ int  sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell);
  * 2H + skin) serves density and force, and stays in use until a particle has moved more than skin/2 from where it
  * was at the rebuild — until then no unlisted pair can be inside the support 2H, and listed pairs beyond 2H
  * contribute exactly 0.  Results do not depend on the skin (beyond summation order).  skin = 0: rebuild every step.
- * The skin is a fraction of 2H, process-wide, read by sph_create / sph_create_slab (default: $SPH_SKIN or 0). */
+ * The skin is a fraction of 2H, process-wide, read by sph_create / sph_create_slab (default: $SPH_SKIN or 0.15). */
 int   sph_set_default_skin(float fraction_of_2h);
 float sph_default_skin(void);
 /* cell length of the device grid for these parameters and the current default skin (what slab hosts must bin with) */

@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_HIP = os.path.join(HERE, "csrc", "libsph_hip.so")
+LIB_HIP = os.environ.get("SPH_LIB_HIP") or os.path.join(HERE, "csrc", "libsph_hip.so")   # override: A/B builds only
 LIB_HOST = os.path.join(HERE, "host", "libsph_host.so")
 
 # byte-compatible with the reference's `struct particle` (pi_sph_fluid.c:26-31)

@@ -51,13 +51,15 @@ struct sph_ctx {
 
 namespace {
 
-// process-wide default skin as a fraction of 2H (sph_set_default_skin / $SPH_SKIN); < 0 = not set yet
+// process-wide default skin as a fraction of 2H (sph_set_default_skin / $SPH_SKIN); < 0 = not set yet.
+// 0.15 measured best on the 2M-particle dam break (0.03 ... 0.3 are within 15 % of it).
+constexpr float SKIN_FRAC_DEFAULT = 0.15f;
 float g_skin_frac = -1.0f;
 float default_skin_frac() {
     if (g_skin_frac < 0.0f) {
         const char *e = getenv("SPH_SKIN");
-        const float v = e ? (float)atof(e) : 0.0f;
-        g_skin_frac = (v >= 0.0f && v <= 1.0f) ? v : 0.0f;
+        const float v = e ? (float)atof(e) : SKIN_FRAC_DEFAULT;
+        g_skin_frac = (v >= 0.0f && v <= 1.0f) ? v : SKIN_FRAC_DEFAULT;
     }
     return g_skin_frac;
 }

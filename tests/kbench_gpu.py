@@ -1,6 +1,6 @@
 """Manual kernel timing (not collected by pytest): cfg2 after warm-up, back-to-back launches of the two heavy
-kernels, then the force-kernel ablation builds (SPH_ABLATE: 1 = no hit loops, 2 = no staging, 3 = neither).
-Usage: python tests/kbench_gpu.py [warmup_steps]"""
+kernels, then the force-kernel ablation builds (SPH_ABLATE bits: 1 = gathers read one address, 2 = no pair
+arithmetic, 4 = no staging).  Usage: [SPH_SKIN=f] [SPH_LIB_HIP=path] python tests/kbench_gpu.py [warmup_steps]"""
 import importlib
 import os
 import sys
@@ -14,8 +14,9 @@ os.environ.pop("SPH_ABLATE", None)
 ctx = sph.Context(prm, f, b)
 ctx.step(warm)
 ctx.sync()
+print("lib %s skin %.3f rebuilds/direct tiles %s" % (os.path.basename(sph.LIB_HIP), sph.default_skin(), ctx.rebuild_stats()))
 print("density %.2f us" % (ctx.time_kernel("density_eos", 50) * 1e3))
-for abl in ("0", "1", "2", "3", "7", "15", "0"):
+for abl in ("0", "1", "2", "3", "4", "6", "7", "0"):
     os.environ["SPH_ABLATE"] = abl
     print("force SPH_ABLATE=%s : %.2f us" % (abl, ctx.time_kernel("force_kick", 50) * 1e3))
 os.environ.pop("SPH_ABLATE", None)

@@ -1,0 +1,153 @@
+"""Neighbour-list reuse (Verlet skin) on a real MI355X, through the C ABI.
+
+The reference rebuilds its linked list every step (pi_sph_fluid.c:626).  The product rebuilds its sort + neighbour
+lists only when a particle has moved more than skin/2 since the last rebuild; until then no unlisted pair can be
+inside the support and listed pairs beyond it contribute exactly 0.  These tests pin that claim:
+  * reused lists give the same rho and a as an exact walk over the cell ranges of the same state (variant 1),
+  * trajectories do not depend on the skin beyond summation order, and match the oracle at the G5 tolerances,
+  * skin = 0 rebuilds every step, skin > 0 rebuilds less often than every step.
+"""
+import numpy as np
+import pytest
+
+from conftest import GX, GY, boundary_particles, load_golden, particles
+
+pytestmark = pytest.mark.gpu
+
+
+def m_fluid(prm):
+    return np.float32(prm.rho0) * np.float32(prm.vol)
+
+
+@pytest.fixture
+def skin(sph):
+    """set the process-wide default skin for one test, restore it afterwards."""
+    old = sph.default_skin()
+
+    def _set(v):
+        sph.set_default_skin(v)
+    yield _set
+    sph.set_default_skin(old)
+
+
+def block_scene(sph, orc):
+    g = load_golden("block.npz")
+    box = tuple(g["box"])
+    xy = g["fluid_xy0"]
+    state = np.concatenate([xy, np.zeros_like(xy)], 1)
+    prm = sph.default_params(box)
+    return prm, particles(orc, state, m_fluid(prm)), boundary_particles(orc, g["boundary_xy"]), g
+
+
+def lists_vs_exact_walk(ctx, tag):
+    """rho and a from the (possibly reused) neighbour lists vs an exact walk over the cell ranges (variant 1) on the
+    same state.  a is evaluated by both from the SAME stored rho, p (the staged gate G3: p = B((rho/rho0)^7 - 1)
+    amplifies a last-bit difference of rho by 1e8), on the scale of the sum of its terms ~ 0.05 p [m/s^2]."""
+    ctx.set_variant(0)
+    ctx.eval_density()
+    rho_list = ctx.read_particles()["rho"]
+    ctx.set_variant(1)
+    ctx.eval_density()
+    ctx.eval_pressure()
+    ref = ctx.read_particles()
+    ctx.eval_accel(GX, GY)
+    bdu, bdv = ctx.read_accel()
+    ctx.set_variant(0)
+    ctx.eval_accel(GX, GY)
+    adu, adv = ctx.read_accel()
+    assert np.max(np.abs(rho_list - ref["rho"]) / ref["rho"]) <= 2e-6, tag
+    scale = 0.05 * (ref["p"] + ref["p"].mean()) + np.hypot(bdu, bdv) + 9.81
+    assert np.max(np.hypot(adu - bdu, adv - bdv) / scale) <= 1e-4, tag
+
+
+@pytest.mark.parametrize("frac", [0.05, 0.15, 0.4])
+def test_reused_lists_equal_exact_walk(sph, orc, skin, frac):
+    skin(frac)
+    prm, f, b, g = block_scene(sph, orc)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        rows, cols, cell = ctx.device_grid()
+        assert abs(cell - 2 * prm.h * (1 + frac)) <= 1e-6
+        r0, _ = ctx.rebuild_stats()
+        done = 0
+        for k in (7, 60, 200, 400):
+            ctx.step(k - done, GX, GY)
+            done = k
+            ctx.sync()
+            lists_vs_exact_walk(ctx, (frac, k))
+        r1, direct = ctx.rebuild_stats()
+        assert 0 < r1 - r0 < done, (r0, r1)          # rebuilt at least once, and not every step
+        assert direct == 0
+
+
+def test_skin_zero_rebuilds_every_step(sph, orc, skin):
+    skin(0.0)
+    prm, f, b, g = block_scene(sph, orc)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        r0, _ = ctx.rebuild_stats()
+        ctx.step(50, GX, GY)
+        ctx.sync()
+        r1, _ = ctx.rebuild_stats()
+        assert r1 - r0 == 50
+        kt = ctx.profile_steps(5, GX, GY)
+        assert kt["rebuilds_per_step"] == 1.0
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.15, 0.4])
+def test_trajectory_does_not_depend_on_skin(sph, orc, oracle, skin, frac):
+    """300 steps of the 14 400-particle dam break against the oracle, and the default scene against the golden
+    trajectory (G5), under different skins."""
+    skin(frac)
+    prm, f, b, g = block_scene(sph, orc)
+    box = tuple(g["box"])
+    p = oracle.params(box)
+    ob = boundary_particles(orc, g["boundary_xy"], g["psi"])
+    of = f.copy()
+    du, dv = oracle.eval(p, of, ob, GX, GY)
+    oracle.steps(p, of, ob, GX, GY, du, dv, 300)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.step(300, GX, GY)
+        ctx.sync()
+        got = ctx.read_particles()
+    assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-4
+    assert np.max(np.abs(got["rho"] - of["rho"]) / of["rho"]) <= 1e-3
+
+    gd = load_golden("drop.npz")
+    prm = sph.default_params((0.0, 4.0, 0.0, 2.0))
+    f = particles(orc, gd["state_0"], m_fluid(prm))
+    b = boundary_particles(orc, gd["boundary_xy"])
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        done = 0
+        for k, tol in [(10, 1e-6), (100, 1e-5), (1000, 1e-3)]:
+            ctx.step(k - done, GX, GY)
+            done = k
+            ctx.sync()
+            got = ctx.read_particles()
+            st = gd["state_%d" % k]
+            dx = max(np.abs(got["x"] - st[:, 0]).max(), np.abs(got["y"] - st[:, 1]).max())
+            assert dx <= tol, (frac, k, dx)
+
+
+def test_fast_random_particles(sph, orc, skin):
+    """random gas with velocities up to 40 m/s (c/10, the reference's design limit): particles cross a skin in a
+    step or two, so rebuilds must be triggered on time; checked against the exact walk every few steps."""
+    rng = np.random.default_rng(11)
+    n = 6000
+    box = (0.0, 6.0, 0.0, 6.0)
+    prm = sph.default_params(box)
+    # jittered lattice (no coincident particles), random velocities
+    side = int(np.sqrt(n))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    xy = 0.5 + 0.064 * np.stack([gx.ravel(), gy.ravel()], 1) + rng.uniform(-0.02, 0.02, (side * side, 2))
+    uv = rng.uniform(-40.0, 40.0, (side * side, 2)) * (rng.random((side * side, 1)) < 0.2)
+    state = np.concatenate([xy, uv], 1).astype(np.float32)
+    f = particles(orc, state, m_fluid(prm))
+    prm2, _, walls = sph.scene_disc(box, 3.0, 3.0, 0.1)
+    for frac in (0.1, 0.3):
+        skin(frac)
+        with sph.Context(prm, f, walls, 0.0, 0.0) as ctx:
+            for k in range(12):
+                ctx.step(3, 0.0, 0.0)
+                ctx.sync()
+                lists_vs_exact_walk(ctx, (frac, k))
+            got = ctx.read_particles()
+            assert np.all(np.isfinite(got["x"])) and np.all(np.isfinite(got["rho"]))
