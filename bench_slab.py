@@ -28,6 +28,12 @@ class HostStagedTransport:
         self.rl = torch.zeros(slab.words, dtype=torch.int32)
         self.rr = torch.zeros(slab.words, dtype=torch.int32)
 
+    def reduce_flag(self):
+        if self.world > 1:
+            f = self.torch.tensor([self.slab.flag_get()], dtype=self.torch.int32)
+            self.dist.all_reduce(f, op=self.dist.ReduceOp.MAX)
+            self.slab.flag_set(int(f.item()))
+
     def exchange(self):
         t, d, ops = self.torch, self.dist, []
         if self.rank > 0:

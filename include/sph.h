@@ -167,14 +167,20 @@ int  sph_set_variant(sph_ctx *ctx, int variant);
 
 /* ---- multi-GPU: x-slab domain decomposition, one process per GPU ----
  * The reference has no distributed path; this is the sharding of its particle loops (:272, :311) by cell column.
- * A slab owns the cell columns [col_begin, col_end) of the global grid (:94) and keeps 2 ghost columns per side.
- * One exchange per step: after kick+drift each slab hands each neighbour the particles now inside that
- * neighbour's reach (its own 2 outermost columns + anything that just migrated across), as fixed-capacity
- * buffers: uint32 header[4] = {count,0,0,0} followed by records of 5 words {x, y, u, v, id}.  The host moves the
- * buffers (RCCL send/recv over xGMI through torch.distributed, or any other transport) between
- *     sph_slab_step_begin()   kick 1/2 + drift + halo pack                (:615-624)
- *     sph_slab_step_end()     ingest + sort + density + EOS + force + kick (:626-640)
- * Ownership follows position: after the sort a slab owns whatever lies in its columns. */
+ * A slab owns the cell columns [col_begin, col_end) of the device grid (sph_device_cell) and keeps 2 ghost columns
+ * per side.  One halo exchange per step, as fixed-capacity buffers: uint32 header[4] = {count, kind, 0, 0}, then
+ *   kind 0 (a step that rebuilds the neighbour structure): records of 5 words {x, y, u, v, id} — every particle now
+ *          inside the neighbour's reach (this slab's 2 outermost owned columns + anything that migrated across since
+ *          the last rebuild); ownership follows position: after the sort a slab owns whatever lies in its columns;
+ *   kind 1 (any other step): records of 4 words {x, y, u, v} — the 2 outermost owned columns in array order, which
+ *          is the order of the neighbour's ghost columns (interface cells are kept sorted by particle id).
+ * All slabs must rebuild in the same step, so the rebuild request is ONE 32-bit word per slab that the host
+ * MAX-reduces over all ranks each step (RCCL all-reduce on the device word, or any other transport):
+ *     sph_slab_step_begin()   kick 1/2 + drift of the owned particles; raises the word when lists may be stale (:615-624)
+ *     -- reduce the word over all ranks --
+ *     sph_slab_step_pack()    fills the send buffers (kind 0 or 1 according to the word)
+ *     -- move send_right -> right neighbour's recv_left, send_left -> left neighbour's recv_right --
+ *     sph_slab_step_end()     ingest + sort + lists (kind 0) or ghost update (kind 1), density + EOS + force + kick (:626-640) */
 typedef struct sph_slab_desc {
     int col_begin, col_end;      /* owned global cell columns [begin, end), at least 4 */
     int has_left, has_right;     /* a neighbouring slab exists */
@@ -188,7 +194,14 @@ int  sph_create_slab(sph_ctx **out, const sph_params *prm, const sph_slab_desc *
                      const sph_particle *fluid, const uint32_t *ids, int n_fluid,
                      const sph_particle *boundary_all, int n_boundary_all, float gx, float gy, int device);
 int  sph_slab_step_begin(sph_ctx *ctx, float gx, float gy);
+int  sph_slab_step_pack(sph_ctx *ctx);
 int  sph_slab_step_end(sph_ctx *ctx);
+/* the rebuild word: its device address (library-owned unless replaced), adopting a word of the host framework
+ * (e.g. a 1-element int32 torch tensor handed to RCCL; NULL = back to the library's own), host-staged access */
+int  sph_slab_flag_buffer(sph_ctx *ctx, void **dev_word);
+int  sph_slab_set_flag_buffer(sph_ctx *ctx, void *dev_word);
+int  sph_slab_flag_get(sph_ctx *ctx, uint32_t *value);
+int  sph_slab_flag_set(sph_ctx *ctx, uint32_t value);
 /* device addresses and byte size of the four halo buffers (library-owned unless replaced below) */
 int  sph_slab_buffers(sph_ctx *ctx, void **send_left, void **send_right, void **recv_left, void **recv_right, size_t *bytes);
 /* adopt device buffers of the host framework (e.g. torch tensors handed to RCCL); each >= the size above */

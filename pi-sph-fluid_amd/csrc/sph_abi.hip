@@ -27,7 +27,7 @@ struct sph_ctx {
     int n = 0, nb = 0;          // single mode: fluid / boundary counts; slab mode: n = particles passed at creation
     int cap = 0;                // capacity of the particle arrays (== n in single mode)
     bool slab = false;
-    bool slab_mid_step = false; // between sph_slab_step_begin and sph_slab_step_end
+    int slab_phase = 0;         // 0 idle, 1 after sph_slab_step_begin, 2 after sph_slab_step_pack
     bool own_halo = false;      // halo buffers allocated by the library (else adopted from the host framework)
     size_t halo_bytes = 0;
     uint32_t *d_ids = nullptr;  // slab read-back staging
@@ -41,8 +41,6 @@ struct sph_ctx {
     size_t bytes = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
-    hipGraph_t sgraph[2] = {nullptr, nullptr};       // slab mode: [0] = step_begin, [1] = step_end
-    hipGraphExec_t sgexec[2] = {nullptr, nullptr};
     bool use_graph = true;
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
     long long oob_total = 0, nan_total = 0;
@@ -147,11 +145,11 @@ size_t padded_items(const Consts &c) {
 void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (ev) (void)hipEventRecord(ev[SPH_K_KICK_DRIFT], st);
-    launch_kick_drift(st, ctx->c, ctx->a, ctx->cap);
+    launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, false);
     if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
     launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);       // the rebuild kernels: no-ops unless requested
     if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.flags);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
     if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
@@ -166,55 +164,6 @@ void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
 void drop_graph(sph_ctx *ctx) {
     if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
     if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
-    for (int k = 0; k < 2; k++) {
-        if (ctx->sgexec[k]) { (void)hipGraphExecDestroy(ctx->sgexec[k]); ctx->sgexec[k] = nullptr; }
-        if (ctx->sgraph[k]) { (void)hipGraphDestroy(ctx->sgraph[k]); ctx->sgraph[k] = nullptr; }
-    }
-}
-
-// the two halves of a slab step (everything except the gravity upload, which carries this call's arguments)
-int enqueue_slab_half(sph_ctx *ctx, int half) {
-    hipStream_t st = ctx->stream;
-    if (half == 0) {
-        for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, HALO_HDR * sizeof(uint32_t), st));
-        launch_kick_drift_key(st, ctx->c, ctx->a, ctx->cap);
-    } else {
-        launch_ingest(st, ctx->c, ctx->a, ctx->cap);      // also requests the rebuild below (every step in slab mode)
-        launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.flags);
-        launch_reorder(st, ctx->c, ctx->a, ctx->cap);
-        launch_build_list(st, ctx->c, ctx->a, ctx->cap);
-        launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
-        launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
-    }
-    return SPH_OK;
-}
-
-// Measured on MI355X: replaying two short graphs per step is SLOWER than ~11 eager launches (4622 vs 5417 steps/s at
-// 2M particles: hipGraphLaunch's fixed cost, MI355X_MICROARCH.md "graph-replay-floor"), so slab halves are launched
-// eagerly unless SPH_SLAB_GRAPH=1.  (sph_step's single graph per step does pay: the host loop is in C.)
-int run_slab_half(sph_ctx *ctx, int half) {
-    static const bool want_graph = getenv("SPH_SLAB_GRAPH") && getenv("SPH_SLAB_GRAPH")[0] == '1';
-    if (!want_graph) return enqueue_slab_half(ctx, half);
-    if (ctx->use_graph && !ctx->sgexec[half]) {
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            (void)enqueue_slab_half(ctx, half);
-            hipError_t e = hipStreamEndCapture(ctx->stream, &ctx->sgraph[half]);
-            if (e == hipSuccess) e = hipGraphInstantiate(&ctx->sgexec[half], ctx->sgraph[half], nullptr, nullptr, 0);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                drop_graph(ctx);
-                ctx->use_graph = false;
-            }
-        } else {
-            (void)hipGetLastError();
-            ctx->use_graph = false;
-        }
-    }
-    if (ctx->use_graph && ctx->sgexec[half]) {
-        HIPCHK(ctx, hipGraphLaunch(ctx->sgexec[half], ctx->stream));
-        return SPH_OK;
-    }
-    return enqueue_slab_half(ctx, half);
 }
 
 // capture one step into a graph (launch-latency bound at small N; replay costs one submission)
@@ -243,8 +192,9 @@ int resort_state(sph_ctx *ctx) {
     hipStream_t st = ctx->stream;
     launch_set_rebuild(st, ctx->a, true);
     launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.velt);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.flags);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+    if (ctx->slab) launch_canon(st, ctx->c, ctx->a);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     launch_set_rebuild(st, ctx->a, false);
     HIPCHK(ctx, hipMemcpyAsync(ctx->a.velt, ctx->a.vel, sizeof(float2) * (size_t)ctx->cap, hipMemcpyDeviceToDevice, st));
@@ -255,12 +205,16 @@ int check_flags(sph_ctx *ctx) {
     uint32_t h[FLAG_COUNT] = {0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h[FLAG_OOB] | h[FLAG_NAN] | h[FLAG_CAPACITY]) {
+    if (h[FLAG_OOB] | h[FLAG_NAN] | h[FLAG_CAPACITY] | h[FLAG_MISMATCH]) {
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags, 0, 2 * sizeof(uint32_t), ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_CAPACITY, 0, sizeof(uint32_t), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_MISMATCH, 0, sizeof(uint32_t), ctx->stream));
         ctx->oob_total += h[FLAG_OOB];
         ctx->nan_total += h[FLAG_NAN];
         if (h[FLAG_NAN]) return fail(ctx, SPH_E_NAN, "particle positions became NaN/Inf");
+        if (h[FLAG_MISMATCH])
+            return fail(ctx, SPH_E_STATE, "halo message does not match this step (neighbouring slabs out of step, or the rebuild "
+                                          "word was not reduced over all ranks before sph_slab_step_pack)");
         if (h[FLAG_CAPACITY]) return fail(ctx, SPH_E_CAPACITY, "slab particle or halo capacity exceeded");
         return fail(ctx, SPH_E_OUT_OF_DOMAIN, ctx->slab ? "particles left the slab's local grid and were clamped into edge cells"
                                                         : "particles left the domain and were clamped into edge cells");
@@ -389,6 +343,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
+    a.rebuild = a.flags + FLAG_REBUILD;
     HIPCHK(ctx, hipMemsetAsync(a.acc, 0, (n ? n : 1) * sizeof(float2), st));
     if (slab)
         for (int k = 0; k < 2; k++) {
@@ -405,7 +360,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemcpyAsync(bpos_in, hb.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
     launch_set_rebuild(st, a, true);        // the scan is a rebuild kernel
     launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.dirty, a.flags, n_boundary);
-    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.flags);
+    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild);
     launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary);
     if (psi_given) {
         // psi was computed on the full wall set (a slab sees only its part of the walls): scatter it to bin order
@@ -720,25 +675,77 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
 // ---- slab decomposition ----
 int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
-    if (!ctx->slab || ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_step_begin: not a slab context or already mid-step");
+    if (!ctx->slab || ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_step_begin: not a slab context or already mid-step");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     launch_set_gravity(st, ctx->a, gx, gy);
-    int rc = run_slab_half(ctx, 0);
-    if (rc) return rc;
+    launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, true);      // owned range; raises the rebuild word when lists may be stale
     HIPCHK(ctx, hipGetLastError());
-    ctx->slab_mid_step = true;
+    ctx->slab_phase = 1;
+    return SPH_OK;
+}
+
+int sph_slab_step_pack(sph_ctx *ctx) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (!ctx->slab || ctx->slab_phase != 1) return fail(ctx, SPH_E_STATE, "sph_slab_step_pack without sph_slab_step_begin");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, HALO_HDR * sizeof(uint32_t), st));
+    launch_key_owned_pack(st, ctx->c, ctx->a, ctx->cap);        // rebuild step: full records (ghosts + migration)
+    launch_pack_update(st, ctx->c, ctx->a);                     // other steps: x, y, u, v of the interface columns
+    HIPCHK(ctx, hipGetLastError());
+    ctx->slab_phase = 2;
     return SPH_OK;
 }
 
 int sph_slab_step_end(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
-    if (!ctx->slab || !ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_begin");
+    if (!ctx->slab || ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_pack");
     (void)hipSetDevice(ctx->device);
-    int rc = run_slab_half(ctx, 1);
-    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    launch_ingest(st, ctx->c, ctx->a, ctx->cap);                // rebuild step only (like the next four)
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
+    launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+    launch_canon(st, ctx->c, ctx->a);
+    launch_build_list(st, ctx->c, ctx->a, ctx->cap);
+    launch_unpack_update(st, ctx->c, ctx->a);                   // other steps only
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
+    launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
-    ctx->slab_mid_step = false;
+    ctx->slab_phase = 0;
+    return SPH_OK;
+}
+
+int sph_slab_flag_buffer(sph_ctx *ctx, void **dev_word) {
+    if (!ctx || !ctx->slab || !dev_word) return SPH_E_ARG;
+    *dev_word = ctx->a.rebuild;
+    return SPH_OK;
+}
+
+int sph_slab_set_flag_buffer(sph_ctx *ctx, void *dev_word) {
+    if (!ctx || !ctx->slab || !ctx->stream) return SPH_E_ARG;
+    if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_set_flag_buffer mid-step");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->a.rebuild = dev_word ? static_cast<uint32_t *>(dev_word) : ctx->a.flags + FLAG_REBUILD;
+    HIPCHK(ctx, hipMemsetAsync(ctx->a.rebuild, 0, sizeof(uint32_t), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPH_OK;
+}
+
+int sph_slab_flag_get(sph_ctx *ctx, uint32_t *value) {
+    if (!ctx || !ctx->slab || !ctx->stream || !value) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipMemcpyAsync(value, ctx->a.rebuild, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SPH_OK;
+}
+
+int sph_slab_flag_set(sph_ctx *ctx, uint32_t value) {
+    if (!ctx || !ctx->slab || !ctx->stream) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_set_rebuild(ctx->stream, ctx->a, value != 0u);
+    HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
 
@@ -755,10 +762,9 @@ int sph_slab_buffers(sph_ctx *ctx, void **send_left, void **send_right, void **r
 int sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void *recv_left, void *recv_right, size_t bytes) {
     if (!ctx || !ctx->slab || !send_left || !send_right || !recv_left || !recv_right) return SPH_E_ARG;
     if (bytes < ctx->halo_bytes) return fail(ctx, SPH_E_ARG, "sph_slab_set_buffers: buffers smaller than the halo capacity");
-    if (ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_set_buffers mid-step");
+    if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_set_buffers mid-step");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    drop_graph(ctx);          // the halo buffer addresses are baked into the captured step graphs
     ctx->a.send[0] = static_cast<uint32_t *>(send_left);
     ctx->a.send[1] = static_cast<uint32_t *>(send_right);
     ctx->a.recv[0] = static_cast<uint32_t *>(recv_left);
@@ -790,7 +796,7 @@ int sph_slab_copy_in(sph_ctx *ctx, int side, const void *host) {
 
 int sph_slab_read(sph_ctx *ctx, sph_particle *out, uint32_t *ids, float *du_dt, float *dv_dt, int cap, int *n_out) {
     if (!ctx || !ctx->stream || !ctx->slab || !n_out) return SPH_E_ARG;
-    if (ctx->slab_mid_step) return fail(ctx, SPH_E_STATE, "sph_slab_read mid-step");
+    if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_read mid-step");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     launch_export_owned(st, ctx->c, ctx->a, ctx->cap, ctx->d_aos, ctx->d_ids, ctx->d_du, ctx->d_dv);
@@ -811,11 +817,15 @@ int sph_slab_read(sph_ctx *ctx, sph_particle *out, uint32_t *ids, float *du_dt, 
 int sph_slab_counts(sph_ctx *ctx, int *n_local, int *n_owned) {
     if (!ctx || !ctx->stream || !ctx->slab) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
-    uint32_t hdn[4] = {0, 0, 0, 0};
+    // local = everything in the sorted arrays; owned = the range of the owned columns (as of the last rebuild)
+    uint32_t hdn[4] = {0, 0, 0, 0}, lo = 0, hi = 0;
+    const Consts &c = ctx->c;
     HIPCHK(ctx, hipMemcpyAsync(hdn, ctx->a.dn, sizeof hdn, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&lo, ctx->a.cell_start + (size_t)c.ghost * c.rows, sizeof lo, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&hi, ctx->a.cell_start + (size_t)(c.ghost + c.owned) * c.rows, sizeof hi, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (n_local) *n_local = (int)hdn[0];
-    if (n_owned) *n_owned = (int)hdn[1];
+    if (n_owned) *n_owned = (int)(hi - lo);
     return SPH_OK;
 }
 

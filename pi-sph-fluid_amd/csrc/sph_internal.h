@@ -76,6 +76,8 @@ struct Arrays {
     // misc
     float2 *grav;       // gravity vector read by the force kernel
     uint32_t *flags;    // see FLAG_*
+    uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
+                        // that it MAX-reduces over all ranks between kick/drift and the halo pack
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
     // slab halo buffers: uint32 header[4] = {count,..} + halo_cap records of 5 words (x, y, u, v, id)
     uint32_t *send[2], *recv[2];   // [0] = left neighbour, [1] = right neighbour
@@ -90,7 +92,8 @@ enum {
     FLAG_REBUILD = 5,       // set by kick/drift (or the host): the rebuild kernels of this step run; cleared by density
     FLAG_NREBUILD = 6,      // rebuilds so far
     FLAG_DIRECT_TILES = 7,  // tiles put on the direct path by list builds so far
-    FLAG_COUNT = 8
+    FLAG_MISMATCH = 8,      // slab mode: a halo message did not match the step (kind or length): ranks out of step
+    FLAG_COUNT = 12
 };
 constexpr int TILE_WORDS = 16;           // 32-bit words per tile record
 constexpr int LIST_WORDS_PER_TILE = 24 * 256;   // LROWS2 x BLK (sph_list.inc static_asserts this)
@@ -108,10 +111,15 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy);
 // read on the device from a.dn[0], so slab mode (count changes every step) and single mode share the kernels.
 // set / clear flags[FLAG_REBUILD] from the host side of the stream
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
-// single-GPU step: first half kick + drift in place (:615-624); requests a rebuild when the lists may be stale
-void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap);
-// slab mode: first half kick + drift + cell key + histogram into the staging arrays + halo pack
-void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// first half kick + drift in place (:615-624; slab mode: the owned range); requests a rebuild when the lists may be stale
+void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab);
+// slab mode, rebuild step: keys + histogram of the owned range into the staging arrays + full-record halo pack
+void launch_key_owned_pack(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// slab mode, other steps: position/velocity updates of the interface columns (no-ops on a rebuild step)
+void launch_pack_update(hipStream_t st, const Consts &c, const Arrays &a);
+void launch_unpack_update(hipStream_t st, const Consts &c, const Arrays &a);
+// slab mode, rebuild step: canonical (by id) particle order inside the cells of the interface columns
+void launch_canon(hipStream_t st, const Consts &c, const Arrays &a);
 // rebuild: keys + histogram of (pos, vsrc, id) as they are, into the staging arrays
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc);
 // slab mode: append the received halo records to the staging arrays, then dn[0] = owned + received
@@ -121,7 +129,7 @@ void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int c
                          float *du, float *dv);
 // rebuild kernels (no-ops unless flags[FLAG_REBUILD]): scan, scatter, tile records + neighbour lists
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
-                 uint32_t *block_sums, const uint32_t *flags);
+                 uint32_t *block_sums, const uint32_t *rebuild);
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 void launch_build_list(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 // variant: 0 = LDS-tiled neighbour lists (default), 1 = direct global loads over the cell ranges (A/B measurements)

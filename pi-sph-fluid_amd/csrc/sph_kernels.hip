@@ -70,9 +70,9 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy) {
     hipLaunchKernelGGL(k_set_gravity, dim3(1), dim3(1), 0, st, a.grav, gx, gy);
 }
 
-__global__ void k_set_flag(uint32_t *flags, int which, uint32_t value) { flags[which] = value; }
+__global__ void k_set_word(uint32_t *word, uint32_t value) { *word = value; }
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
-    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, st, a.flags, (int)FLAG_REBUILD, on ? 1u : 0u);
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, on ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -80,12 +80,18 @@ void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
 // they hold every pair that can come within 2H while no particle has moved more than skin/2 from its pos_ref.
 // The first particle beyond that (or any motion at all with skin = 0, or a NaN) requests a rebuild, which the
 // rebuild kernels queued behind this one carry out in the same step.
+template <bool SLAB>
 __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict__ pos, const float2 *__restrict__ pos_ref,
                                                     const float2 *__restrict__ acc, const float2 *__restrict__ velt,
-                                                    float2 *__restrict__ vel, uint32_t *__restrict__ flags,
-                                                    const uint32_t *__restrict__ dn) {
-    const int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= (int)dn[0]) return;
+                                                    float2 *__restrict__ vel, const uint32_t *__restrict__ cs,
+                                                    uint32_t *__restrict__ rebuild, const uint32_t *__restrict__ dn) {
+    // slab mode: only the OWNED range of the sorted arrays moves (cell_start of the last rebuild); the ghosts are
+    // refreshed from their owners by the halo exchange of this step
+    const int src0 = SLAB ? (int)cs[c.ghost * c.rows] : 0;
+    const int n = SLAB ? (int)cs[(c.ghost + c.owned) * c.rows] - src0 : (int)dn[0];
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (t >= n) return;
+    const int i = src0 + t;
     const float2 a = acc[i], r = pos_ref[i];
     float2 v = velt[i], p = pos[i];
     v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
@@ -97,23 +103,23 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
     const float dx = p.x - r.x, dy = p.y - r.y;
     const bool moved = !(fmaf(dx, dx, dy * dy) <= c.lim2);      // true for NaN too
     if (__ballot(moved) != 0ull && (threadIdx.x & 63) == (int)__builtin_ctzll(__ballot(1)))
-        flags[FLAG_REBUILD] = 1u;
+        *rebuild = 1u;
 }
 
-void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab) {
     if (cap <= 0) return;
-    hipLaunchKernelGGL(k_kick_drift, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel,
-                       a.flags, a.dn);
+    dim3 g((cap + BLK - 1) / BLK), b(BLK);
+    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.rebuild, a.dn);
+    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.rebuild, a.dn);
 }
 
 // ------------------------------------------------------------------------------------------
 // P1: key + histogram into the staging arrays (rebuild kernel).  44 B/particle + 4 B slot.
-// !INTEGRATE (single GPU, init, upload): take entries 0..dn[0]-1 of (pos, vsrc, id) as they are.
-// INTEGRATE (slab mode): read the OWNED range of the sorted arrays (cell_start of the previous sort), kick 1/2 +
-// drift (:615-624), write staging entries 0..n_own-1.
-// SLAB: also append every particle now inside a neighbour's reach (its two outermost owned columns, plus the
-// column it may just have migrated into) to that neighbour's halo buffer: ONE exchange per step carries both the
-// ghosts and the ownership migration.
+// !SLAB (single GPU; init and upload in either mode): entries 0..dn[0]-1 of (pos, vsrc, id) as they are.
+// SLAB (a slab's rebuild step): the OWNED range of the sorted arrays (cell_start of the previous rebuild) becomes
+// staging entries 0..n_own-1, and every particle now inside a neighbour's reach (this slab's two outermost owned
+// columns, plus the column it may have migrated into since the last rebuild) is appended to that neighbour's halo
+// buffer as a full record: ONE exchange carries both the ghosts and the ownership migration.
 DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, uint32_t id, uint32_t *__restrict__ flags) {
     const uint32_t k = atomicAdd(&buf[0], 1u);
     if (k < (uint32_t)cap) {
@@ -126,20 +132,19 @@ DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, ui
     }
 }
 
-template <bool INTEGRATE, bool SLAB>
-__global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *__restrict__ pos,
-                                                        const uint32_t *__restrict__ id, const float2 *__restrict__ acc,
-                                                        const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs,
-                                                        float2 *__restrict__ velk, float4 *__restrict__ pk,
-                                                        uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
-                                                        uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
-                                                        uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
-                                                        uint32_t *__restrict__ send_r) {
-    if (!INTEGRATE && flags[FLAG_REBUILD] == 0u) return;      // rebuild kernel
+template <bool SLAB>
+__global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__restrict__ pos, const uint32_t *__restrict__ id,
+                                                  const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs,
+                                                  float2 *__restrict__ velk, float4 *__restrict__ pk,
+                                                  uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
+                                                  uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
+                                                  const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
+                                                  uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r) {
+    if (*rebuild == 0u) return;      // rebuild kernel
     const int t = blockIdx.x * BLK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int src0 = 0, n;
-    if (INTEGRATE) {
+    if (SLAB) {
         src0 = (int)cs[c.ghost * c.rows];
         n = (int)cs[(c.ghost + c.owned) * c.rows] - src0;
         if (t == 0) dn[1] = (uint32_t)n;
@@ -156,18 +161,11 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
         p = pos[i];
         v = vsrc[i];
         pid = id[i];
-        if (INTEGRATE) {
-            float2 a = acc[i];
-            v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
-            v.y = fmaf(c.half_dt, a.y, v.y);
-            p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
-            p.y = fmaf(c.dt, v.y, p.y);
-        }
         int row;
         cell_of(c, p.x, p.y, row, col, oob, bad);
         key = (uint32_t)(col * c.rows + row);
     }
-    // The array is in last step's cell order and a particle moves << one cell per step, so
+    // The array is in the last rebuild's cell order and a particle moves << one cell between rebuilds, so
     // neighbouring lanes mostly share their new cell.  One histogram atomic per run of equal
     // keys (run head adds the run length, members take consecutive slots) instead of one per
     // particle: ~7x fewer atomics and no same-address serialisation inside the wave.
@@ -192,32 +190,125 @@ __global__ __launch_bounds__(BLK) void k_kick_drift_key(Consts c, const float2 *
         velk[t] = v;
         if (bad) atomicAdd(&flags[FLAG_NAN], 1u);
         else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
-        if (SLAB && INTEGRATE && !bad) {
+        if (SLAB && !bad) {
             if (c.has_left && col < c.ghost + 2) halo_append(send_l, c.halo_cap, p, v, pid, flags);
             if (c.has_right && col >= c.ghost + c.owned - 2) halo_append(send_r, c.halo_cap, p, v, pid, flags);
         }
     }
 }
 
-#define KDK_ARGS(vsrc) c, a.pos, a.id, a.acc, vsrc, a.cell_start, a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.dn, a.send[0], a.send[1]
-void launch_kick_drift_key(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+#define KH_ARGS(vsrc) c, a.pos, a.id, vsrc, a.cell_start, a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1]
+void launch_key_owned_pack(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     if (cap <= 0) return;
-    dim3 g((cap + BLK - 1) / BLK), b(BLK);
-    if (c.has_left || c.has_right) hipLaunchKernelGGL((k_kick_drift_key<true, true>), g, b, 0, st, KDK_ARGS(a.velt));
-    else hipLaunchKernelGGL((k_kick_drift_key<true, false>), g, b, 0, st, KDK_ARGS(a.velt));
+    hipLaunchKernelGGL((k_key_hist<true>), dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, KH_ARGS(a.vel));
 }
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc) {
     if (cap <= 0) return;
-    hipLaunchKernelGGL((k_kick_drift_key<false, false>), dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, KDK_ARGS(vsrc));
+    hipLaunchKernelGGL((k_key_hist<false>), dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, KH_ARGS(vsrc));
 }
-#undef KDK_ARGS
+#undef KH_ARGS
+
+// ------------------------------------------------------------------------------------------
+// slab mode, steps WITHOUT a rebuild: the local particle set and its order are unchanged, so a ghost only needs its
+// owner's new position and velocity.  Both sides keep the cells of the interface columns in a canonical order (by
+// particle id, k_canon), so the owner's two outermost owned columns and the neighbour's two ghost columns are the
+// SAME sequence of particles: the update is a plain copy of a contiguous range, 16 bytes per particle.
+// Buffer header: {count, kind, 0, 0}, kind 0 = full records (rebuild step), 1 = update.
+__global__ __launch_bounds__(BLK) void k_pack_update(Consts c, const float2 *__restrict__ pos, const float2 *__restrict__ vel,
+                                                     const uint32_t *__restrict__ cs, const uint32_t *__restrict__ rebuild,
+                                                     uint32_t *__restrict__ flags, uint32_t *__restrict__ send_l,
+                                                     uint32_t *__restrict__ send_r) {
+    if (*rebuild != 0u) return;      // a rebuild step sends full records instead (k_key_hist<true>)
+    const int side = blockIdx.y;
+    if (side == 0 ? !c.has_left : !c.has_right) return;
+    const int col0 = side == 0 ? c.ghost : c.ghost + c.owned - 2;
+    const int beg = (int)cs[col0 * c.rows], n = (int)cs[(col0 + 2) * c.rows] - beg;
+    uint32_t *buf = side == 0 ? send_l : send_r;
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (t == 0) {
+        buf[0] = (uint32_t)min(n, c.halo_cap);
+        buf[1] = 1u;
+        if (n > c.halo_cap) atomicAdd(&flags[FLAG_CAPACITY], 1u);
+    }
+    if (t >= n || t >= c.halo_cap) return;
+    const float2 p = pos[beg + t], v = vel[beg + t];
+    reinterpret_cast<float4 *>(buf + HALO_HDR)[t] = make_float4(p.x, p.y, v.x, v.y);
+}
+
+__global__ __launch_bounds__(BLK) void k_unpack_update(Consts c, float2 *__restrict__ pos, float2 *__restrict__ vel,
+                                                       const uint32_t *__restrict__ cs, const uint32_t *__restrict__ rebuild,
+                                                       uint32_t *__restrict__ flags, const uint32_t *__restrict__ recv_l,
+                                                       const uint32_t *__restrict__ recv_r) {
+    if (*rebuild != 0u) return;
+    const int side = blockIdx.y;
+    if (side == 0 ? !c.has_left : !c.has_right) return;
+    const int col0 = side == 0 ? 0 : c.ghost + c.owned;
+    const int beg = (int)cs[col0 * c.rows], n = (int)cs[(col0 + c.ghost) * c.rows] - beg;
+    const uint32_t *buf = side == 0 ? recv_l : recv_r;
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    // the neighbour must have sent an update of exactly my ghost range (same rebuild step, same canonical order)
+    if (t == 0 && (buf[0] != (uint32_t)n || buf[1] != 1u)) atomicAdd(&flags[FLAG_MISMATCH], 1u);
+    if (t >= n || t >= (int)buf[0]) return;
+    const float4 q = reinterpret_cast<const float4 *>(buf + HALO_HDR)[t];
+    pos[beg + t] = make_float2(q.x, q.y);
+    vel[beg + t] = make_float2(q.z, q.w);
+}
+
+void launch_pack_update(hipStream_t st, const Consts &c, const Arrays &a) {
+    if (c.halo_cap <= 0) return;
+    hipLaunchKernelGGL(k_pack_update, dim3((c.halo_cap + BLK - 1) / BLK, 2), dim3(BLK), 0, st, c, a.pos, a.vel, a.cell_start,
+                       a.rebuild, a.flags, a.send[0], a.send[1]);
+}
+void launch_unpack_update(hipStream_t st, const Consts &c, const Arrays &a) {
+    if (c.halo_cap <= 0) return;
+    hipLaunchKernelGGL(k_unpack_update, dim3((c.halo_cap + BLK - 1) / BLK, 2), dim3(BLK), 0, st, c, a.pos, a.vel, a.cell_start,
+                       a.rebuild, a.flags, a.recv[0], a.recv[1]);
+}
+
+// slab mode, rebuild step, after the scatter: put every cell of the interface columns (two ghost + two owned columns
+// on each side) into ascending particle-id order.  Both neighbours hold the same particles in those cells, so after
+// this their sequences agree and updates can be exchanged as contiguous ranges.  One thread per cell, selection sort
+// in place (a cell holds ~7 particles).
+__global__ __launch_bounds__(BLK) void k_canon(Consts c, float2 *__restrict__ pos, float2 *__restrict__ pos_ref,
+                                               float2 *__restrict__ vel, uint32_t *__restrict__ id,
+                                               const uint32_t *__restrict__ cs, const uint32_t *__restrict__ rebuild) {
+    if (*rebuild == 0u) return;
+    const int span = (c.ghost + 2) * c.rows;          // cells per side
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (t >= 2 * span) return;
+    const bool right = t >= span;
+    if (right ? !c.has_right : !c.has_left) return;
+    const int cell = right ? (c.ghost + c.owned - 2) * c.rows + (t - span) : t;
+    const uint32_t beg = cs[cell], end = cs[cell + 1];
+    for (uint32_t a = beg; a + 1 < end; a++) {
+        uint32_t m = a, mid = id[a];
+        for (uint32_t b = a + 1; b < end; b++) {
+            const uint32_t v = id[b];
+            if (v < mid) { mid = v; m = b; }
+        }
+        if (m != a) {
+            const float2 p = pos[a], r = pos_ref[a], v = vel[a];
+            const uint32_t ia = id[a];
+            pos[a] = pos[m]; pos_ref[a] = pos_ref[m]; vel[a] = vel[m]; id[a] = mid;
+            pos[m] = p; pos_ref[m] = r; vel[m] = v; id[m] = ia;
+        }
+    }
+}
+void launch_canon(hipStream_t st, const Consts &c, const Arrays &a) {
+    if (!(c.has_left || c.has_right)) return;
+    const int work = 2 * (c.ghost + 2) * c.rows;
+    hipLaunchKernelGGL(k_canon, dim3((work + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.pos_ref, a.vel, a.id, a.cell_start,
+                       a.rebuild);
+}
 
 // slab mode: the records received from the two neighbours join the staging arrays behind the owned particles
 __global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__restrict__ recv_l,
                                                 const uint32_t *__restrict__ recv_r, float2 *__restrict__ velk,
                                                 float4 *__restrict__ pk, uint32_t *__restrict__ slot,
                                                 uint32_t *__restrict__ count, uint32_t *__restrict__ dirty,
-                                                uint32_t *__restrict__ flags, uint32_t *__restrict__ dn, int stage_cap) {
+                                                uint32_t *__restrict__ flags, const uint32_t *__restrict__ rebuild,
+                                                uint32_t *__restrict__ dn, int stage_cap) {
+    if (*rebuild == 0u) return;      // rebuild kernel (other steps: k_unpack_update)
     const int n_own = (int)dn[1];
     const int nl = c.has_left ? min((int)recv_l[0], c.halo_cap) : 0;
     const int nr = c.has_right ? min((int)recv_r[0], c.halo_cap) : 0;
@@ -228,7 +319,7 @@ __global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__rest
         if ((c.has_left && (int)recv_l[0] > c.halo_cap) || (c.has_right && (int)recv_r[0] > c.halo_cap))
             atomicAdd(&flags[FLAG_CAPACITY], 1u);
         dn[0] = (uint32_t)total;
-        flags[FLAG_REBUILD] = 1u;      // slab mode re-sorts and re-lists every step (the local particle set changes)
+        if ((c.has_left && recv_l[1] != 0u) || (c.has_right && recv_r[1] != 0u)) atomicAdd(&flags[FLAG_MISMATCH], 1u);
     }
     if (t >= nl + nr) return;
     const int dst = n_own + t;
@@ -250,7 +341,7 @@ __global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__rest
 void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap) {
     const int work = 2 * c.halo_cap;
     hipLaunchKernelGGL(k_ingest, dim3((work + BLK - 1) / BLK > 0 ? (work + BLK - 1) / BLK : 1), dim3(BLK), 0, st, c, a.recv[0],
-                       a.recv[1], a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.dn, stage_cap);
+                       a.recv[1], a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, stage_cap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -279,9 +370,9 @@ DEV uint32_t block_sum_256(uint32_t v, uint32_t *lds4) {
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__restrict__ count,
                                                             const uint32_t *__restrict__ dirty,
                                                             uint32_t *__restrict__ block_sums,
-                                                            const uint32_t *__restrict__ flags) {
+                                                            const uint32_t *__restrict__ rebuild) {
     __shared__ uint32_t red[4];
-    if (flags[FLAG_REBUILD] == 0u) return;      // rebuild kernel
+    if (*rebuild == 0u) return;      // rebuild kernel
     if (dirty[blockIdx.x] == 0u) {      // untouched since it was last zeroed: all counts are 0
         if (threadIdx.x == 0) block_sums[blockIdx.x] = 0u;
         return;
@@ -297,10 +388,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
                                                            const uint32_t *__restrict__ block_sums,
                                                            uint32_t *__restrict__ dirty,
                                                            uint32_t *__restrict__ cell_start, int n_items,
-                                                           const uint32_t *__restrict__ flags) {
+                                                           const uint32_t *__restrict__ rebuild) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t wave_tot[4];
-    if (flags[FLAG_REBUILD] == 0u) return;      // rebuild kernel
+    if (*rebuild == 0u) return;      // rebuild kernel
     // offset of this tile = sum of the tiles before it (<= a few thousand L2-resident words)
     uint32_t off = 0;
     for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_BLOCK) off += block_sums[k];
@@ -353,11 +444,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
 }
 
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
-                 uint32_t *block_sums, const uint32_t *flags) {
+                 uint32_t *block_sums, const uint32_t *rebuild) {
     int n_items = c.n_cells + 1;
     int tiles = (n_items + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, dirty, block_sums, flags);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums, dirty, cell_start, n_items, flags);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, dirty, block_sums, rebuild);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums, dirty, cell_start, n_items, rebuild);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -367,8 +458,8 @@ __global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, 
                                                  const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
                                                  float2 *__restrict__ pos_ref, float2 *__restrict__ vel,
                                                  uint32_t *__restrict__ id, uint32_t *__restrict__ skey,
-                                                 const uint32_t *__restrict__ dn, const uint32_t *__restrict__ flags) {
-    if (flags[FLAG_REBUILD] == 0u) return;
+                                                 const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild) {
+    if (*rebuild == 0u) return;
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= (int)dn[0]) return;
     float4 q = pk[i];
@@ -385,7 +476,7 @@ void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     (void)c;
     if (cap <= 0) return;
     hipLaunchKernelGGL(k_reorder, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, a.pk, a.velk, a.slot, a.cell_start, a.pos,
-                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.flags);
+                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.rebuild);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -408,9 +499,9 @@ __global__ __launch_bounds__(BLK) void k_density_direct(Consts c, const float2 *
                                                         const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
                                                         const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
                                                         float2 *__restrict__ rp, float *__restrict__ prs,
-                                                        uint32_t *__restrict__ flags, const uint32_t *__restrict__ dn) {
+                                                        uint32_t *__restrict__ rebuild, const uint32_t *__restrict__ dn) {
     int i = blockIdx.x * BLK + threadIdx.x;
-    if (i == 0) flags[FLAG_REBUILD] = 0u;       // a rebuild request has been served by the kernels before this one
+    if (i == 0) *rebuild = 0u;       // a rebuild request has been served by the kernels before this one
     if (i >= (int)dn[0]) return;
     float2 pi = pos[i];
     int row, col;
@@ -554,10 +645,10 @@ void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, i
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
     if (mode == DENS_RHO_EOS)
         hipLaunchKernelGGL(k_density_direct<true>, g, b, 0, st, c, a.pos, a.skey, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, a.flags, a.dn);
+                           a.rp, a.prs, a.rebuild, a.dn);
     else
         hipLaunchKernelGGL(k_density_direct<false>, g, b, 0, st, c, a.pos, a.skey, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, a.flags, a.dn);
+                           a.rp, a.prs, a.rebuild, a.dn);
 }
 
 void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool kick, int variant) {

@@ -2,18 +2,22 @@
 
 The reference has no distributed path.  Its particle loops (pi_sph_fluid.c:272, :311) shard by cell
 column: a slab owns the global cell columns [c0, c1) and keeps two ghost columns per side, so ONE
-exchange per step (after kick+drift) carries both the ghosts and the ownership migration.  This
-module is backend-agnostic host logic:
+exchange per step (after kick+drift) carries both the ghosts and the ownership migration.  All slabs
+rebuild their neighbour structure in the same step: each raises a 32-bit "rebuild" word when its
+lists may be stale, the host MAX-reduces the word over all ranks, and the halo message of the step
+is a set of full records (rebuild step) or a plain position/velocity update of the interface
+columns (any other step).  This module is backend-agnostic host logic:
 
   partition_columns()  column ranges with ~equal particle counts (quantiles of the per-column histogram)
   local_subset()       the particles a slab starts with (owned + ghosts) and their global ids
   GpuSlab              the C-ABI slab context (sph_create_slab ... sph_slab_read)
   LocalTransport       in-process exchange between several slabs on one device (tests, 1 GPU)
   TorchTransport       torch.distributed P2P (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" on CPU)
-  SlabRunner           step loop: begin -> exchange -> end
+  SlabRunner           step loop: begin -> reduce the rebuild word -> pack -> exchange -> end
 
-Halo buffer format (include/sph.h): uint32 header[4] = {count,0,0,0} then records of 5 words
-{x, y, u, v, id}; fixed capacity, always sent whole (messages are 0.1-1 MB: latency-bound on xGMI).
+Halo buffer format (include/sph.h): uint32 header[4] = {count, kind, 0, 0} then `count` records of
+5 words {x, y, u, v, id} (kind 0) or 4 words {x, y, u, v} (kind 1); fixed capacity, always sent
+whole (messages are 0.1-1 MB: latency-bound on xGMI).
 """
 import ctypes as C
 
@@ -135,8 +139,28 @@ class GpuSlab:
     def step_begin(self, gx, gy):
         self._chk(self.L.sph_slab_step_begin(self.h, gx, gy))
 
+    def step_pack(self):
+        self._chk(self.L.sph_slab_step_pack(self.h))
+
     def step_end(self):
         self._chk(self.L.sph_slab_step_end(self.h))
+
+    # the rebuild word
+    def flag_get(self):
+        v = C.c_uint32()
+        self._chk(self.L.sph_slab_flag_get(self.h, C.byref(v)))
+        return int(v.value)
+
+    def flag_set(self, value):
+        self._chk(self.L.sph_slab_flag_set(self.h, int(value)))
+
+    def flag_tensor(self, torch, device):
+        """a 1-element int32 tensor of the host framework adopted as the rebuild word (all-reduced by the transport)."""
+        if getattr(self, "_flag_t", None) is None:
+            t = torch.zeros(1, dtype=torch.int32, device=device)
+            self._chk(self.L.sph_slab_set_flag_buffer(self.h, C.c_void_p(t.data_ptr())))
+            self._flag_t = t
+        return self._flag_t
 
     def sync(self):
         self._chk(self.L.sph_sync(self.h))
@@ -187,6 +211,13 @@ class LocalTransport:
     def __init__(self, slabs):
         self.slabs = slabs
 
+    def reduce_flag(self):
+        s = self.slabs
+        if len(s) > 1:
+            any_set = max(x.flag_get() for x in s)
+            for x in s:
+                x.flag_set(any_set)
+
     def exchange(self):
         s = self.slabs
         for r in range(len(s) - 1):
@@ -204,6 +235,12 @@ class TorchTransport:
     def __init__(self, torch, dist, slab, rank, world, device):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
         self.send_l, self.send_r, self.recv_l, self.recv_r = slab.halo_tensors(torch, device)
+        self.flag = slab.flag_tensor(torch, device)
+
+    def reduce_flag(self):
+        """all slabs rebuild in the same step: MAX over ranks of the 4-byte rebuild word (stays on the device)."""
+        if self.world > 1:
+            self.dist.all_reduce(self.flag, op=self.dist.ReduceOp.MAX)
 
     def exchange(self):
         d, ops = self.dist, []
@@ -219,7 +256,8 @@ class TorchTransport:
 
 
 class SlabRunner:
-    """nsteps of: kick/drift + halo pack -> exchange -> ingest + sort + density + force (pi_sph_fluid.c:612-641)."""
+    """nsteps of: kick/drift -> reduce the rebuild word -> halo pack -> exchange -> (ingest + sort + lists | ghost
+    update) + density + force (pi_sph_fluid.c:612-641)."""
 
     def __init__(self, slabs, transport):
         self.slabs = slabs if isinstance(slabs, (list, tuple)) else [slabs]
@@ -229,6 +267,9 @@ class SlabRunner:
         for _ in range(nsteps):
             for s in self.slabs:
                 s.step_begin(gx, gy)
+            self.transport.reduce_flag()
+            for s in self.slabs:
+                s.step_pack()
             self.transport.exchange()
             for s in self.slabs:
                 s.step_end()

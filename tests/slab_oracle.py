@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: a CPU slab backend built on the oracle, with the same interface as the product's GpuSlab
-(step_begin / step_end / halo_tensors / read), so that the product's host-side slab logic (partitioner, halo
+(step_begin / step_pack / step_end / halo_tensors / flag_tensor / read), so that the product's host-side slab logic (partitioner, halo
 protocol, TorchTransport, SlabRunner) can be exercised by world_size-2 gloo tests without a GPU.
 
 The backend keeps its local arrays ordered by global particle id, so the oracle's neighbour summation order
@@ -54,13 +54,26 @@ class OracleSlab:
         rec[:, 4] = self.ids[sel]
         buf[4:4 + 5 * n] = rec.ravel()
 
+    def flag_tensor(self, torch, device):
+        """the rebuild word: this backend rebuilds (and sends full records) every step, like the reference (:626)."""
+        if getattr(self, "_flag", None) is None:
+            self._flag = torch.zeros(1, dtype=torch.int32)
+        return self._flag
+
     def step_begin(self, gx, gy):
         self.g = (gx, gy)
+        if getattr(self, "_flag", None) is not None:
+            self._flag[0] = 1
         o = self.own
         o["u"] = (o["u"].astype(np.float64) + self.half_dt * self.du.astype(np.float64)).astype(np.float32)   # :616
         o["v"] = (o["v"].astype(np.float64) + self.half_dt * self.dv.astype(np.float64)).astype(np.float32)
         o["x"] = o["x"] + self.dt * o["u"]                                                                     # :622
         o["y"] = o["y"] + self.dt * o["v"]
+
+    def step_pack(self):
+        if getattr(self, "_flag", None) is not None:
+            assert int(self._flag[0]) == 1            # MAX over ranks of words that are all 1
+        o = self.own
         gc = self.sph.slab.global_columns(self.prm, o["x"])
         self._pack(self.bufs[0], (gc < self.c0 + 2) if self.has_left else np.zeros(len(o), bool))
         self._pack(self.bufs[1], (gc >= self.c1 - 2) if self.has_right else np.zeros(len(o), bool))

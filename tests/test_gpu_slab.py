@@ -78,17 +78,69 @@ def test_slab_errors(sph):
     L = sph.hip_lib()
     assert L.sph_step(s.h, 0.0, -9.81, 1) == sph.SPH_E_STATE          # single-GPU entry point on a slab
     assert L.sph_slab_step_end(s.h) == sph.SPH_E_STATE                # end without begin
+    assert L.sph_slab_step_pack(s.h) == sph.SPH_E_STATE               # pack without begin
     s.step_begin(GX, GY)
     assert L.sph_slab_step_begin(s.h, 0.0, -9.81) == sph.SPH_E_STATE
+    assert L.sph_slab_step_end(s.h) == sph.SPH_E_STATE                # end without pack
+    s.step_pack()
     s.step_end()
     s.close()
     with pytest.raises(sph.SphError):
         sph.slab.GpuSlab(sph, prm, f, b, 10, 12, True, True, GX, GY)   # < 4 owned columns
     # a halo buffer that is too small is reported, not overrun
     t = sph.slab.GpuSlab(sph, prm, f, b, 0, 60, False, True, GX, GY, halo_capacity=16)
+    t.flag_set(1)            # a rebuild step sends full records of the two outermost columns: more than 16
     t.step_begin(GX, GY)
+    t.step_pack()
     t.step_end()
     with pytest.raises(sph.SphError) as e:
         t.sync()
     assert e.value.code == sph.SPH_E_CAPACITY
     t.close()
+
+
+def test_slab_reuses_lists_between_rebuilds(sph, orc):
+    """with a skin the slabs rebuild together and rarely; in between the halo carries plain updates.  Same gates as
+    the every-step protocol, plus: rebuild counts agree across slabs and are smaller than the step count."""
+    g = load_golden("block.npz")
+    prm = sph.default_params(tuple(g["box"]))
+    f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))      # developed flow, |v| up to 20 m/s
+    b = boundary_particles(orc, g["boundary_xy"])
+    old = sph.default_skin()
+    try:
+        for frac in (0.0, 0.2):
+            sph.set_default_skin(frac)
+            slabs, runner = build(sph, prm, f, b, 3)
+            with sph.Context(prm, f, b, GX, GY) as ctx:
+                ctx.step(20, GX, GY)
+                ctx.sync()
+                ref20 = ctx.read_particles()
+                ctx.step(100, GX, GY)
+                ctx.sync()
+                ref = ctx.read_particles()
+            runner.step(20, GX, GY)
+            out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+            assert np.all(seen == 1), frac
+            assert max(np.abs(out["x"] - ref20["x"]).max(), np.abs(out["y"] - ref20["y"]).max()) <= 2e-5, frac
+            assert np.max(np.abs(out["rho"] - ref20["rho"]) / ref20["rho"]) <= 2e-4, frac
+            runner.step(100, GX, GY)
+            for s in slabs:
+                s.sync()
+            out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+            assert np.all(seen == 1), frac
+            # summation order only, amplified by the chaotic developed flow (as in test_developed_block_slabs_vs_single)
+            assert max(np.abs(out["x"] - ref["x"]).max(), np.abs(out["y"] - ref["y"]).max()) <= 2e-3, frac
+            assert np.max(np.abs(out["rho"] - ref["rho"]) / ref["rho"]) <= 2e-2, frac
+            L = sph.hip_lib()
+            import ctypes as C
+            counts = []
+            for s in slabs:
+                a, d = C.c_longlong(), C.c_longlong()
+                assert L.sph_rebuild_stats(s.h, C.byref(a), C.byref(d)) == 0
+                counts.append(a.value)
+            assert len(set(counts)) == 1, counts                      # all slabs rebuilt in the same steps
+            assert (counts[0] - 1 == 120) if frac == 0.0 else (1 < counts[0] - 1 < 120), (frac, counts)
+            for s in slabs:
+                s.close()
+    finally:
+        sph.set_default_skin(old)

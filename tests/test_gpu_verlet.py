@@ -131,17 +131,17 @@ def test_fast_random_particles(sph, orc, skin):
     """random gas with velocities up to 40 m/s (c/10, the reference's design limit): particles cross a skin in a
     step or two, so rebuilds must be triggered on time; checked against the exact walk every few steps."""
     rng = np.random.default_rng(11)
-    n = 6000
-    box = (0.0, 6.0, 0.0, 6.0)
+    box = (0.0, 16.0, 0.0, 16.0)
     prm = sph.default_params(box)
-    # jittered lattice (no coincident particles), random velocities
-    side = int(np.sqrt(n))
+    # jittered lattice at the reference spacing in the middle of a large box (nobody reaches the walls), one
+    # particle in five moving at up to 40 m/s
+    side = 70
     gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
-    xy = 0.5 + 0.064 * np.stack([gx.ravel(), gy.ravel()], 1) + rng.uniform(-0.02, 0.02, (side * side, 2))
+    xy = 5.4 + 0.075 * np.stack([gx.ravel(), gy.ravel()], 1) + rng.uniform(-0.02, 0.02, (side * side, 2))
     uv = rng.uniform(-40.0, 40.0, (side * side, 2)) * (rng.random((side * side, 1)) < 0.2)
     state = np.concatenate([xy, uv], 1).astype(np.float32)
     f = particles(orc, state, m_fluid(prm))
-    prm2, _, walls = sph.scene_disc(box, 3.0, 3.0, 0.1)
+    prm2, _, walls = sph.scene_disc(box, 8.0, 8.0, 0.1)
     for frac in (0.1, 0.3):
         skin(frac)
         with sph.Context(prm, f, walls, 0.0, 0.0) as ctx:
