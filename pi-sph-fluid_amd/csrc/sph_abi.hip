@@ -39,8 +39,14 @@ struct sph_ctx {
     unsigned char *d_bits = nullptr;  // 8192 metaball pixels
     std::vector<void *> allocs;
     size_t bytes = 0;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
+    // Single-GPU step with the list kernels: the force pass of step s also does step s+1's kick 1/2 + drift into the
+    // alternate arrays (a.pos2, a.vel2); step s+1 starts by swapping the two sets.  primed: the alternate set holds
+    // that look-ahead (false after creation / upload / eval_accel / variant change: the next step then starts with
+    // the stand-alone kick/drift kernel instead).  One captured graph per orientation of the two sets.
+    bool primed = false;
+    float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
     bool use_graph = true;
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
     long long oob_total = 0, nan_total = 0;
@@ -141,13 +147,15 @@ size_t padded_items(const Consts &c) {
     return (n_items + SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
 }
 
-// the launches of one time step (SPH_K_* order); ev != nullptr records an event before each
-void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
+bool fused(const sph_ctx *ctx) { return !ctx->slab && ctx->variant == 0; }
+
+// What a step launches after its kick/drift (SPH_K_* order; ev != nullptr records an event before each): the rebuild
+// kernels (no-ops unless requested), density + EOS, force + kick.  With the list kernels the force pass also
+// integrates the next step's kick 1/2 + drift (FORCE_KICK_DRIFT).
+void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
-    if (ev) (void)hipEventRecord(ev[SPH_K_KICK_DRIFT], st);
-    launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, false);
     if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
-    launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);       // the rebuild kernels: no-ops unless requested
+    launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
     if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
     launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
     if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
@@ -155,36 +163,58 @@ void enqueue_step(sph_ctx *ctx, hipEvent_t *ev) {
     if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
-    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true);
     if (ev) (void)hipEventRecord(ev[SPH_K_FORCE_KICK], st);
-    launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
+    launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     if (ev) (void)hipEventRecord(ev[SPH_K_HALO], st);   // = end of step
 }
 
 void drop_graph(sph_ctx *ctx) {
-    if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
-    if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+    for (int k = 0; k < 2; k++) {
+        if (ctx->gexec[k]) { (void)hipGraphExecDestroy(ctx->gexec[k]); ctx->gexec[k] = nullptr; }
+        if (ctx->graph[k]) { (void)hipGraphDestroy(ctx->graph[k]); ctx->graph[k] = nullptr; }
+    }
 }
 
-// capture one step into a graph (launch-latency bound at small N; replay costs one submission)
-bool ensure_graph(sph_ctx *ctx) {
-    if (!ctx->use_graph) return false;
-    if (ctx->gexec) return true;
+// the step body captured into a graph for the current orientation of the two position/velocity sets
+// (launch-latency bound at small N; replay costs one submission)
+hipGraphExec_t step_graph(sph_ctx *ctx) {
+    if (!ctx->use_graph) return nullptr;
+    const int k = ctx->a.pos == ctx->pos_a ? 0 : 1;
+    if (ctx->gexec[k]) return ctx->gexec[k];
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         ctx->use_graph = false;
-        return false;
+        return nullptr;
     }
-    enqueue_step(ctx, nullptr);
-    hipError_t e = hipStreamEndCapture(ctx->stream, &ctx->graph);
-    if (e == hipSuccess) e = hipGraphInstantiate(&ctx->gexec, ctx->graph, nullptr, nullptr, 0);
+    enqueue_step_body(ctx, nullptr);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &ctx->graph[k]);
+    if (e == hipSuccess) e = hipGraphInstantiate(&ctx->gexec[k], ctx->graph[k], nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         drop_graph(ctx);
         ctx->use_graph = false;
-        return false;
+        return nullptr;
     }
-    return true;
+    return ctx->gexec[k];
+}
+
+// one time step (:612-641).  Kick 1/2 + drift: already done by the previous step's force pass (swap the sets), or
+// the stand-alone kernel.
+int run_step(sph_ctx *ctx, hipEvent_t *ev) {
+    hipStream_t st = ctx->stream;
+    if (ev) (void)hipEventRecord(ev[SPH_K_KICK_DRIFT], st);
+    if (fused(ctx) && ctx->primed) {
+        std::swap(ctx->a.pos, ctx->a.pos2);
+        std::swap(ctx->a.vel, ctx->a.vel2);
+    } else {
+        launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, false);
+    }
+    ctx->primed = fused(ctx);
+    hipGraphExec_t g = ev ? nullptr : step_graph(ctx);
+    if (g) HIPCHK(ctx, hipGraphLaunch(g, st));
+    else enqueue_step_body(ctx, ev);
+    return SPH_OK;
 }
 
 // rebuild from the current (pos, velt, id) state: keys + histogram, scan, scatter, neighbour lists; then velt := sorted vel
@@ -318,7 +348,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     const size_t n = (size_t)ctx->cap, nb = (size_t)n_boundary, pad = padded_items(ctx->c);
     const size_t tiles = pad / SCAN_TILE;
 #define ALLOC(ptr, cnt) if ((rc = dalloc(ctx, &(ptr), (cnt))) != SPH_OK) return rc
-    ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
+    ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.pos2, n); ALLOC(a.vel2, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
     ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.skey, n); ALLOC(a.pos_ref, n);
     const size_t ntiles = (n + 255) / 256 + 9;
     ALLOC(a.tiles, TILE_WORDS * ntiles); ALLOC(a.nlist, (size_t)LIST_WORDS_PER_TILE * ntiles);
@@ -344,6 +374,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
     a.rebuild = a.flags + FLAG_REBUILD;
+    ctx->pos_a = a.pos;
     HIPCHK(ctx, hipMemsetAsync(a.acc, 0, (n ? n : 1) * sizeof(float2), st));
     if (slab)
         for (int k = 0; k < 2; k++) {
@@ -377,8 +408,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     if (ids) HIPCHK(ctx, hipMemcpyAsync(a.id, ids, (size_t)n_fluid * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     if ((rc = resort_state(ctx)) != SPH_OK) return rc;
     launch_set_gravity(st, a, gx, gy);
-    launch_density(st, ctx->c, a, ctx->cap, DENS_RHO_EOS, ctx->variant);
-    launch_force(st, ctx->c, a, ctx->cap, false, ctx->variant);
+    launch_density(st, ctx->c, a, ctx->cap, DENS_RHO_EOS, ctx->variant, false);
+    launch_force(st, ctx->c, a, ctx->cap, FORCE_EVAL, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(st));   // also keeps hb / fluid alive until the copies are done
     return check_flags(ctx);
@@ -448,10 +479,9 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_step_begin / exchange / sph_slab_step_end");
     (void)hipSetDevice(ctx->device);
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
-    const bool g = ensure_graph(ctx);
     for (int s = 0; s < nsteps; s++) {
-        if (g) HIPCHK(ctx, hipGraphLaunch(ctx->gexec, ctx->stream));
-        else enqueue_step(ctx, nullptr);
+        int rc = run_step(ctx, nullptr);
+        if (rc) return rc;
     }
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
@@ -560,6 +590,7 @@ int sph_set_variant(sph_ctx *ctx, int variant) {
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         drop_graph(ctx);
         ctx->variant = variant;      // both variants work from the same sorted state
+        ctx->primed = false;         // a look-ahead kick/drift of the list kernels is dropped, the current state kept
     }
     return SPH_OK;
 }
@@ -588,6 +619,7 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyHostToDevice, st));
     launch_upload_state(st, ctx->a, ctx->n, ctx->d_aos);
+    ctx->primed = false;
     int rc = resort_state(ctx);
     if (rc) return rc;
     launch_gather_rho_p(st, ctx->c, ctx->a, ctx->n, ctx->d_aos);
@@ -598,7 +630,7 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
 int sph_eval_density(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
-    launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO, ctx->variant);
+    launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO, ctx->variant, false);
     launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, true);   // keep p/rho^2 consistent with the new rho and the stored p
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
@@ -616,7 +648,8 @@ int sph_eval_accel(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
-    launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, false, ctx->variant);
+    launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, FORCE_EVAL, ctx->variant);
+    ctx->primed = false;         // the next step kicks with THIS du_dt (:616), not with a look-ahead made before it
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
@@ -633,7 +666,8 @@ int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_t
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     double acc[SPH_K_COUNT] = {0}, total = 0;
     for (int s = 0; s < nsteps; s++) {
-        enqueue_step(ctx, ctx->ev);
+        int rs = run_step(ctx, ctx->ev);
+        if (rs) return rs;
         HIPCHK(ctx, hipEventSynchronize(ctx->ev[SPH_K_HALO]));
         for (int k = 0; k < SPH_K_HALO; k++) {
             float ms = 0;
@@ -660,8 +694,8 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int r = 0; r < reps; r++) {
-        if (kernel == SPH_K_DENSITY_EOS) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
-        else launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
+        if (kernel == SPH_K_DENSITY_EOS) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false);
+        else launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
@@ -709,8 +743,8 @@ int sph_slab_step_end(sph_ctx *ctx) {
     launch_canon(st, ctx->c, ctx->a);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     launch_unpack_update(st, ctx->c, ctx->a);                   // other steps only
-    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant);
-    launch_force(st, ctx->c, ctx->a, ctx->cap, true, ctx->variant);
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true);
+    launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_phase = 0;
     return SPH_OK;

@@ -49,7 +49,9 @@ struct Consts {
 struct Arrays {
     // fluid, sorted (S)
     float2 *pos;       // x,y
-    float2 *vel;       // u,v (sorted copy read by the force pass)
+    float2 *vel;       // u,v after the first half kick (what the force pass reads)
+    float2 *pos2, *vel2; // the alternate set: the fused force kernel writes the NEXT step's kick 1/2 + drift there and
+                         // sph_abi.hip swaps the two sets at the start of that step
     uint32_t *id;      // original index
     float2 *rp;        // rho, p/rho^2
     float *prs;        // p
@@ -135,9 +137,14 @@ void launch_build_list(hipStream_t st, const Consts &c, const Arrays &a, int cap
 // variant: 0 = LDS-tiled neighbour lists (default), 1 = direct global loads over the cell ranges (A/B measurements)
 // mode: what the density pass writes
 enum { DENS_RHO = 0, DENS_RHO_EOS = 1 };
-void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant);
+// consume_rebuild: this is the density pass of a step, it clears the rebuild word (the rebuild kernels in front of it
+// have served the request)
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild);
+// what the force pass writes besides a: nothing / velt (second half kick) / velt + the next step's kick 1/2 + drift
+// into pos2, vel2 + the next step's rebuild request
+enum { FORCE_EVAL = 0, FORCE_KICK = 1, FORCE_KICK_DRIFT = 2 };
 void launch_eos(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool from_prs);
-void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool kick, int variant);
+void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant);
 // boundary init: bin + pseudo-mass (:600-601, :242-261)
 void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in, uint32_t *key, uint32_t *slot,
                          uint32_t *count, uint32_t *dirty, uint32_t *flags, int nb);

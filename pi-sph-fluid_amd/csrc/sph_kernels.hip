@@ -501,7 +501,7 @@ __global__ __launch_bounds__(BLK) void k_density_direct(Consts c, const float2 *
                                                         float2 *__restrict__ rp, float *__restrict__ prs,
                                                         uint32_t *__restrict__ rebuild, const uint32_t *__restrict__ dn) {
     int i = blockIdx.x * BLK + threadIdx.x;
-    if (i == 0) *rebuild = 0u;       // a rebuild request has been served by the kernels before this one
+    if (rebuild && i == 0) *rebuild = 0u;       // a rebuild request has been served by the kernels before this one
     if (i >= (int)dn[0]) return;
     float2 pi = pos[i];
     int row, col;
@@ -639,23 +639,26 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
 
 namespace sph {
 
-void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant) {
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild) {
     if (cap <= 0) return;
-    if (variant == 0) { launch_density_list(st, c, a, cap, mode); return; }
+    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild); return; }
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
+    uint32_t *rb = consume_rebuild ? a.rebuild : nullptr;
     if (mode == DENS_RHO_EOS)
         hipLaunchKernelGGL(k_density_direct<true>, g, b, 0, st, c, a.pos, a.skey, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, a.rebuild, a.dn);
+                           a.rp, a.prs, rb, a.dn);
     else
         hipLaunchKernelGGL(k_density_direct<false>, g, b, 0, st, c, a.pos, a.skey, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, a.rebuild, a.dn);
+                           a.rp, a.prs, rb, a.dn);
 }
 
-void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool kick, int variant) {
+// mode: FORCE_EVAL / FORCE_KICK / FORCE_KICK_DRIFT (the latter with the list kernels only: sph_abi.hip never asks the
+// direct variant for it)
+void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant) {
     if (cap <= 0) return;
-    if (variant == 0) { launch_force_list(st, c, a, cap, kick); return; }
+    if (variant == 0) { launch_force_list(st, c, a, cap, mode); return; }
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
-    if (kick)
+    if (mode != FORCE_EVAL)
         hipLaunchKernelGGL(k_force_direct<true>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.skey, a.cell_start, a.bpos, a.bpsi,
                            a.bcell_start, a.grav, a.acc, a.velt, a.dn);
     else

@@ -71,9 +71,9 @@ def main():
                 lines.append("| %s | %.0f | %.0f | %.2f | %.2f | %.2f |" % (kn, fs, ws, rd, wr, rd + wr))
         lines.append("")
     # per-launch HBM traffic of the step kernels in bench.py's naming (read side doubled, see above)
-    names = {"k_kick_drift_key<true, false>": "kick_drift_key", "k_reorder": "reorder", "k_density_tiled<1>": "density_eos",
-             "k_force_tiled<true, 0>": "force_kick", "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply",
-             "k_tile_table": "tile_table"}
+    names = {"k_kick_drift<false>": "kick_drift", "k_key_hist<false>": "key_hist", "k_reorder": "reorder",
+             "k_build_list": "build_list", "k_density_list<1>": "density_eos", "k_force_list<true, 0>": "force_kick",
+             "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply"}
     traffic = {}
     for kn, bn in names.items():
         cs = merged.get(kn, {})
