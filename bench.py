@@ -3,8 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg0|cfg4] [--no-cpu]
 
-A "step" is one pass of the hot path (kick/drift + counting sort + density/EOS + force/kick,
-pi_sph_fluid.c:612-641) over every fluid particle of the scene.  Inputs are resident in HBM when
+A "step" is one pass of the hot path (kick/drift, neighbour structure, density/EOS, force/kick:
+pi_sph_fluid.c:612-641) over every fluid particle of the scene.  The neighbour structure (counting
+sort + neighbour lists) is rebuilt when a particle has moved more than half the skin, as decided on
+the device every step; `neighbour_rebuilds_per_step` reports how often that was in the timed run.  Inputs are resident in HBM when
 the timed region starts (sph_create has run); the timed region is exactly K steps, bracketed by a
 device synchronisation (and a barrier across ranks when N > 1), MAX over ranks.
 
@@ -45,10 +47,12 @@ def run_single(sph, name, steps, warmup, profile_steps=20):
     create_s = time.time() - t0
     ctx.step(warmup, 0.0, -9.81)
     ctx.sync()
+    r0, _ = ctx.rebuild_stats()
     t0 = time.perf_counter()
     ctx.step(steps, 0.0, -9.81)
     ctx.sync()
     dt = time.perf_counter() - t0
+    r1, _ = ctx.rebuild_stats()
     kt = ctx.profile_steps(profile_steps, 0.0, -9.81)      # HIP events on the kernels' own stream
     ctx.sync()
     # the two heavy kernels are idempotent: time back-to-back launches on the live state (no per-launch
@@ -62,7 +66,7 @@ def run_single(sph, name, steps, warmup, profile_steps=20):
            "steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
            "mparticle_steps_per_s": steps / dt * n / 1e6, "kernel_ms": kt,
            "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s, "skin_frac": sph.default_skin(),
-           "rebuilds": rebuilds, "direct_tiles": direct_tiles,
+           "rebuilds": rebuilds, "direct_tiles": direct_tiles, "timed_rebuilds_per_step": (r1 - r0) / max(steps, 1),
            "device_mb": ctx.device_bytes() / 1e6}
     ctx.close()
     return res
@@ -160,6 +164,7 @@ def main():
                    "n_fluid": res["n_fluid"], "n_boundary": res["n_boundary"], "grid_cells": res["grid_cells"],
                    "parallelism": "1 GPU"},
         "kernel_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items()},
+        "neighbour_rebuilds_per_step": round(res["timed_rebuilds_per_step"], 4), "skin_fraction_of_2h": round(res["skin_frac"], 4),
         "roofline": roofline(sph, res),
     }
     if not args.no_also and args.workload != "cfg1":
@@ -170,6 +175,7 @@ def main():
                         "value": round(r1["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
                         "timesteps_per_s": round(r1["steps_per_s"], 2), "ms_per_step": round(r1["ms_per_step"], 5),
                         "kernel_ms": {k: round(v, 5) for k, v in r1["kernel_ms"].items()},
+                        "neighbour_rebuilds_per_step": round(r1["timed_rebuilds_per_step"], 4),
                         "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r1["n_fluid"] * r1["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)}]
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sph, args.workload)

@@ -27,8 +27,9 @@ PARTICLE = np.dtype([("x", "<f4"), ("y", "<f4"), ("u", "<f4"), ("v", "<f4"),
 SPH_OK, SPH_E_ARG, SPH_E_HIP, SPH_E_OUT_OF_DOMAIN, SPH_E_NAN = 0, -1, -2, -3, -4
 SPH_E_NOMEM, SPH_E_CAPACITY, SPH_E_STATE = -5, -6, -7
 KERNEL_NAMES = ["kick_drift", "key_hist", "scan", "reorder", "build_list", "density_eos", "force_kick", "halo"]
-# algorithmic HBM bytes per fluid particle per launch (P1 44, P2 5.2, P4 44, P5 16.6, P6 40)
-KERNEL_ALGO_BYTES = {"kick_drift": 44.0, "key_hist": 5.2, "reorder": 44.0, "density_eos": 16.6, "force_kick": 40.0}
+# algorithmic HBM bytes per fluid particle per launch (P1 44 incl. 4 B key, P2 5.2, P4 44, P5 16.6,
+# P6 40).  The single-GPU step's force launch also does the next step's kick 1/2 + drift (P1 without the key): 40 + 40.
+KERNEL_ALGO_BYTES = {"kick_drift": 40.0, "key_hist": 4.0 + 5.2, "reorder": 44.0, "density_eos": 16.6, "force_kick": 40.0 + 40.0}
 STEP_ALGO_BYTES = 152.0
 
 # every symbol include/sph.h and include/sph_host.h declare
