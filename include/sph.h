@@ -131,9 +131,12 @@ int  sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell);
 /* ---- neighbour-structure reuse (Verlet skin) ----
  * The reference rebuilds its linked list every step (:626) and searches it four times per particle (:278, :283,
  * :314, :343).  Here one rebuild (counting sort + per-particle neighbour lists holding every pair closer than
- * 2H + skin) serves density and force, and stays in use until a particle has moved more than skin/2 from where it
- * was at the rebuild — until then no unlisted pair can be inside the support 2H, and listed pairs beyond 2H
- * contribute exactly 0.  Results do not depend on the skin (beyond summation order).  skin = 0: rebuild every step.
+ * 2H + skin) serves density and force, and stays in use while it is provably complete: as long as every particle is
+ * within skin/2 of where it was at the rebuild, or — single GPU — as long as no two particles whose cells were at
+ * most two cells apart have moved more than the skin RELATIVE to each other (checked on per-wave displacement boxes,
+ * so a jet moving as a whole keeps its lists) and nobody has moved more than H + skin.  Until then no unlisted pair
+ * can be inside the support 2H, and listed pairs beyond 2H contribute exactly 0.  Results do not depend on the skin
+ * (beyond summation order).  skin = 0: a rebuild whenever neighbouring particles moved relative to each other at all.
  * The skin is a fraction of 2H, process-wide, read by sph_create / sph_create_slab (default: $SPH_SKIN or 0.15). */
 int   sph_set_default_skin(float fraction_of_2h);
 float sph_default_skin(void);
@@ -141,6 +144,8 @@ float sph_default_skin(void);
 float sph_device_cell(const sph_params *prm);
 /* rebuilds since creation, and tiles that list builds have put on the direct (no list) path */
 int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
+/* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
+int   sph_check_stats(sph_ctx *ctx, long long *checks);
 /* total particles clamped into the domain so far (0 in a healthy run) */
 long long sph_out_of_domain_count(sph_ctx *ctx);
 

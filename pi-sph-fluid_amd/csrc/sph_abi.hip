@@ -109,7 +109,10 @@ int make_consts(const sph_params &p, float skin_frac, Consts &c) {
     const float skin = skin_frac * two_h;
     c.cut_list2 = (two_h + skin) * (two_h + skin);
     c.lim2 = (0.5f * skin) * (0.5f * skin);
-    if (skin > 0.0f) c.lim2 *= 0.999f;      // rounding of the squared distances stays on the safe side
+    c.skin2 = skin * skin;
+    c.cap2 = (p.h + skin) * (p.h + skin);
+    if (skin > 0.0f) { c.lim2 *= 0.999f; c.skin2 *= 0.999f; }      // rounding of the squared distances stays on the safe side
+    c.cap2 *= 0.999f;
     c.nf = (float)nf;
     c.grad_c = (float)(5.0 * nf / (H * H));                              // :56-59
     const double q = p.k2;                                               // W(0.2 H): q = 0.2   :325
@@ -155,6 +158,7 @@ bool fused(const sph_ctx *ctx) { return !ctx->slab && ctx->variant == 0; }
 void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
+    if (!ctx->slab) launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2: do neighbouring waves still move together?
     launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
     if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
     launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
@@ -350,8 +354,10 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
 #define ALLOC(ptr, cnt) if ((rc = dalloc(ctx, &(ptr), (cnt))) != SPH_OK) return rc
     ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.pos2, n); ALLOC(a.vel2, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
     ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.skey, n); ALLOC(a.pos_ref, n);
-    const size_t ntiles = (n + 255) / 256 + 9;
+    const size_t ntiles = (n + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES + 9;
     ALLOC(a.tiles, TILE_WORDS * ntiles); ALLOC(a.nlist, (size_t)LIST_WORDS_PER_TILE * ntiles);
+    const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / 64);
+    ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
     ALLOC(a.dirty, tiles);
@@ -374,6 +380,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
     a.rebuild = a.flags + FLAG_REBUILD;
+    a.check = a.flags + FLAG_CHECK;
     ctx->pos_a = a.pos;
     HIPCHK(ctx, hipMemsetAsync(a.acc, 0, (n ? n : 1) * sizeof(float2), st));
     if (slab)
@@ -575,6 +582,15 @@ int sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (rebuilds) *rebuilds = h[FLAG_NREBUILD];
     if (direct_tiles) *direct_tiles = h[FLAG_DIRECT_TILES];
+    return SPH_OK;
+}
+int sph_check_stats(sph_ctx *ctx, long long *checks) {
+    if (!ctx || !ctx->stream || !checks) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    uint32_t h = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h, ctx->a.flags + FLAG_NCHECK, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *checks = h;
     return SPH_OK;
 }
 long long sph_out_of_domain_count(sph_ctx *ctx) {

@@ -16,7 +16,10 @@ struct Consts {
     float h, inv_h;          // H, 1/H
     float cut2;              // (2H)^2 : support test of :144 on squared distance
     float cut_list2;         // (2H + skin)^2 : a pair enters a neighbour list below this distance (at rebuild time)
-    float lim2;              // (skin/2)^2 : a particle further than this from its rebuild position forces a rebuild
+    float lim2;              // (skin/2)^2 : while nobody is further than this from its rebuild position the lists are valid
+    float skin2;             // skin^2     : ... and beyond that, while neighbouring waves moved less than this RELATIVE to
+                             //              each other (k_check)
+    float cap2;              // (H+skin)^2 : ... and nobody is further than this from its rebuild position
     float nf;                // 7/(4 pi H^2)          :46
     float grad_c;            // 5 nf / H^2 : -dW/dq / (d H) = grad_c * (1-q/2)^3   (:56-59 with q/d = 1/H)
     float inv_w_k2h;         // 1 / W(0.2 H)          :325
@@ -78,6 +81,9 @@ struct Arrays {
     // misc
     float2 *grav;       // gravity vector read by the force kernel
     uint32_t *flags;    // see FLAG_*
+    float4 *wbox;       // per wave (64 consecutive sorted particles): bounding box of displacement since the last rebuild
+    uint32_t *wnbr;     // per wave: WNBR_WORDS words = 5 x {first, last} wave whose particles may come near this wave's
+    uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
@@ -95,10 +101,16 @@ enum {
     FLAG_NREBUILD = 6,      // rebuilds so far
     FLAG_DIRECT_TILES = 7,  // tiles put on the direct path by list builds so far
     FLAG_MISMATCH = 8,      // slab mode: a halo message did not match the step (kind or length): ranks out of step
+    FLAG_CHECK = 9,         // set by the drifting kernel: a particle is beyond skin/2, the wave boxes need comparing
+    FLAG_NCHECK = 10,       // steps in which k_check ran
     FLAG_COUNT = 12
 };
 constexpr int TILE_WORDS = 16;           // 32-bit words per tile record
-constexpr int LIST_WORDS_PER_TILE = 24 * 256;   // LROWS2 x BLK (sph_list.inc static_asserts this)
+constexpr int WNBR_WORDS = 10;           // words per wave in Arrays::wnbr
+#ifndef SPH_TILE_PARTICLES
+#define SPH_TILE_PARTICLES 256           // particles per tile (= threads per workgroup of the list kernels)
+#endif
+constexpr int LIST_WORDS_PER_TILE = 24 * SPH_TILE_PARTICLES;   // LROWS2 x TP (sph_list.inc static_asserts this)
 constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle list padding points at (finite: no NaN)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record
@@ -129,6 +141,9 @@ void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_c
 // slab mode: owned particles (sorted order) -> compact AoS + ids; count left in dn[1]... see sph_abi.hip
 void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int cap, sph_particle *out_dev, uint32_t *ids_dev,
                          float *du, float *dv);
+// single GPU: if the check word is set, compare the displacement boxes of neighbouring waves; raise the rebuild word
+// when two of them moved more than the skin relative to each other
+void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 // rebuild kernels (no-ops unless flags[FLAG_REBUILD]): scan, scatter, tile records + neighbour lists
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
                  uint32_t *block_sums, const uint32_t *rebuild);

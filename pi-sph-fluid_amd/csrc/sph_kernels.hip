@@ -73,44 +73,91 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy) {
 __global__ void k_set_word(uint32_t *word, uint32_t value) { *word = value; }
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
     hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, on ? 1u : 0u);
+    if (!on) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.check, 0u);
 }
 
 // ------------------------------------------------------------------------------------------
-// kick 1/2 + drift in place (:615-624), 48 B/particle.  The neighbour lists were built at pos_ref with a skin:
-// they hold every pair that can come within 2H while no particle has moved more than skin/2 from its pos_ref.
-// The first particle beyond that (or any motion at all with skin = 0, or a NaN) requests a rebuild, which the
-// rebuild kernels queued behind this one carry out in the same step.
+// When must the neighbour structure be rebuilt?  The lists hold every pair closer than L = 2H + skin at the rebuild
+// positions pos_ref; the sort cells are L wide.  Let u_i = pos_i - pos_ref_i.  A pair that is NOT listed
+// (|r_ref| >= L) can only come inside the support 2H if |u_i - u_k| > |r_ref| - 2H.  Hence the lists are valid while
+//   (0) every |u_i| <= skin/2                                        (then |u_i - u_k| <= skin for every pair), or
+//   (1) |u_i - u_k| <= skin for every pair whose sort cells are at most two cells apart (|r_ref| >= L otherwise
+//       irrelevant), AND |u_i| <= H + skin for everybody (pairs three or more cells apart have |r_ref| >= 2L and would
+//       need |u_i - u_k| > 2H + 2 skin).
+// (0) is absolute: one fast jet makes everybody rebuild.  (1) is Galilean-invariant where it matters: a coherent jet
+// keeps its lists.  The drifting kernel evaluates (0) and the cap of (1) per particle and leaves the bounding box of
+// u over each wave (64 consecutive sorted particles) in wbox; only if (0) fails, k_check evaluates the pair part of
+// (1) on the boxes of the waves k_build_list found to be within two cells of each other (conservative: boxes).
+// The direct walks (fallback tiles, variant 1, metaballs) look at 5x5 sort cells, which is exact under the cap alone.
+// Slab mode uses (0) only: the boxes of ghost waves are not known before the halo exchange.
+DEV float wave_min(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+DEV float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+// all 64 lanes of the wave must call this (live = the lane holds a particle); wave = global wave index (slot / 64)
+template <bool SLAB>
+DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int wave, float4 *__restrict__ wbox,
+                       uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild) {
+    const float d2 = fmaf(ux, ux, uy * uy);
+    const bool over = live && !(d2 <= c.lim2);      // true for NaN too
+    if (SLAB) {
+        if (__ballot(over) != 0ull && (threadIdx.x & 63) == 0) *rebuild = 1u;
+        return;
+    }
+    const bool capped = live && !(d2 <= c.cap2);
+    const float inf = __builtin_huge_valf();
+    const float x0 = wave_min(live ? ux : inf), y0 = wave_min(live ? uy : inf);
+    const float x1 = wave_max(live ? ux : -inf), y1 = wave_max(live ? uy : -inf);
+    const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped), any_live = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && any_live != 0ull) {
+        wbox[wave] = make_float4(x0, y0, x1, y1);
+        if (any_over != 0ull) *check = 1u;
+        if (any_cap != 0ull) *rebuild = 1u;
+    }
+}
+
+// kick 1/2 + drift in place (:615-624), 48 B/particle: the stand-alone form (slab mode; single GPU: the first step
+// after creation / upload — afterwards the force pass does this for the next step, sph_list.inc).
 template <bool SLAB>
 __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict__ pos, const float2 *__restrict__ pos_ref,
                                                     const float2 *__restrict__ acc, const float2 *__restrict__ velt,
                                                     float2 *__restrict__ vel, const uint32_t *__restrict__ cs,
+                                                    float4 *__restrict__ wbox, uint32_t *__restrict__ check,
                                                     uint32_t *__restrict__ rebuild, const uint32_t *__restrict__ dn) {
     // slab mode: only the OWNED range of the sorted arrays moves (cell_start of the last rebuild); the ghosts are
     // refreshed from their owners by the halo exchange of this step
     const int src0 = SLAB ? (int)cs[c.ghost * c.rows] : 0;
     const int n = SLAB ? (int)cs[(c.ghost + c.owned) * c.rows] - src0 : (int)dn[0];
     const int t = blockIdx.x * BLK + threadIdx.x;
-    if (t >= n) return;
-    const int i = src0 + t;
-    const float2 a = acc[i], r = pos_ref[i];
-    float2 v = velt[i], p = pos[i];
-    v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
-    v.y = fmaf(c.half_dt, a.y, v.y);
-    p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
-    p.y = fmaf(c.dt, v.y, p.y);
-    pos[i] = p;
-    vel[i] = v;
-    const float dx = p.x - r.x, dy = p.y - r.y;
-    const bool moved = !(fmaf(dx, dx, dy * dy) <= c.lim2);      // true for NaN too
-    if (__ballot(moved) != 0ull && (threadIdx.x & 63) == (int)__builtin_ctzll(__ballot(1)))
-        *rebuild = 1u;
+    const bool live = t < n;
+    const int i = src0 + (live ? t : 0);
+    float ux = 0.0f, uy = 0.0f;
+    if (live) {
+        const float2 a = acc[i], r = pos_ref[i];
+        float2 v = velt[i], p = pos[i];
+        v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
+        v.y = fmaf(c.half_dt, a.y, v.y);
+        p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
+        p.y = fmaf(c.dt, v.y, p.y);
+        pos[i] = p;
+        vel[i] = v;
+        ux = p.x - r.x;
+        uy = p.y - r.y;
+    }
+    drift_verdict<SLAB>(c, ux, uy, live, t >> 6, wbox, check, rebuild);
 }
 
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab) {
     if (cap <= 0) return;
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
-    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.rebuild, a.dn);
-    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.rebuild, a.dn);
+    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.wbox, a.check, a.rebuild, a.dn);
+    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.wbox, a.check, a.rebuild, a.dn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -195,6 +242,35 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
             if (c.has_right && col >= c.ghost + c.owned - 2) halo_append(send_r, c.halo_cap, p, v, pid, flags);
         }
     }
+}
+
+// the pair part of criterion (1): one thread per wave, against every wave k_build_list listed for it
+__global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
+                                               const uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild,
+                                               uint32_t *__restrict__ flags, const uint32_t *__restrict__ dn) {
+    if (*check == 0u) return;
+    const int w = blockIdx.x * BLK + threadIdx.x;
+    if (w == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
+    const int nw = ((int)dn[0] + 63) >> 6;
+    if (w >= nw) return;
+    const float4 b = wbox[w];
+    const uint32_t *nb = wnbr + (size_t)w * WNBR_WORDS;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t first = nb[2 * k], last = nb[2 * k + 1];
+        for (uint32_t o = first; o <= last && o != 0xffffffffu; o++) {      // first > last: nobody in that column
+            const float4 q = wbox[o];
+            const float rx = fmaxf(b.z - q.x, q.z - b.x), ry = fmaxf(b.w - q.y, q.w - b.y);
+            bad |= !(fmaf(rx, rx, ry * ry) <= c.skin2);
+        }
+    }
+    if (bad) *rebuild = 1u;
+}
+void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+    if (cap <= 0) return;
+    const int nw = (cap + 63) / 64;
+    hipLaunchKernelGGL(k_check, dim3((nw + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.check, a.rebuild, a.flags, a.dn);
 }
 
 #define KH_ARGS(vsrc) c, a.pos, a.id, vsrc, a.cell_start, a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1]
@@ -490,27 +566,29 @@ DEV void eos(const Consts &c, float rho, float &p, float &p_over_rho2) {
 }
 
 // ------------------------------------------------------------------------------------------
-// P5 (variant 1, "direct": A/B measurements): one thread per particle, the 3x3 cell ranges of its sort cell read
-// straight from the sorted arrays through L1/L2, exact support test on the current positions (valid between
-// rebuilds: the sort cells are 2H + skin wide and nobody is further than skin/2 from where it was sorted).
+// P5 (variant 1, "direct": A/B measurements and the tests' exact reference walk): one thread per particle, no lists.
+// Fluid neighbours: the 5x5 block of SORT cells around the particle's sort cell, exact support test on the current
+// positions — valid whenever nobody is further than H + skin from where it was sorted (the cap of the rebuild
+// criterion, see drift_verdict).  Boundary neighbours: the 3x3 cells around the particle's CURRENT cell (walls do not
+// move and are binned in the same grid).
 template <bool EOS>
 __global__ __launch_bounds__(BLK) void k_density_direct(Consts c, const float2 *__restrict__ pos,
                                                         const uint32_t *__restrict__ skey,
                                                         const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
                                                         const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
                                                         float2 *__restrict__ rp, float *__restrict__ prs,
-                                                        uint32_t *__restrict__ rebuild, const uint32_t *__restrict__ dn) {
+                                                        uint32_t *__restrict__ rebuild, uint32_t *__restrict__ check,
+                                                        const uint32_t *__restrict__ dn) {
     int i = blockIdx.x * BLK + threadIdx.x;
-    if (rebuild && i == 0) *rebuild = 0u;       // a rebuild request has been served by the kernels before this one
+    if (rebuild && i == 0) { *rebuild = 0u; *check = 0u; }      // served by the kernels before this one
     if (i >= (int)dn[0]) return;
     float2 pi = pos[i];
     int row, col;
     cell_of_key(c, skey[i], row, col);
-    int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
+    const int r0 = max(row - 2, 0), r1 = min(row + 2, c.rows - 1);
     float sf = 0.0f, sb = 0.0f;
-    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
-        int base = cc * c.rows;
-        uint32_t beg = cs[base + r0], end = cs[base + r1 + 1];
+    for (int cc = max(col - 2, 0); cc <= min(col + 2, c.cols - 1); cc++) {
+        const uint32_t beg = cs[cc * c.rows + r0], end = cs[cc * c.rows + r1 + 1];
         for (uint32_t j = beg; j < end; j++) {      // includes j == i: W(0) = nf is the self term of :274-275
             float2 pj = pos[j];
             float dx = pi.x - pj.x, dy = pi.y - pj.y;
@@ -518,7 +596,12 @@ __global__ __launch_bounds__(BLK) void k_density_direct(Consts c, const float2 *
             float w = w_shape(c, d2);
             sf += (d2 < c.cut2) ? w : 0.0f;
         }
-        uint32_t bbeg = bcs[base + r0], bend = bcs[base + r1 + 1];
+    }
+    bool oob, bad;
+    cell_of(c, pi.x, pi.y, row, col, oob, bad);
+    const int b0 = max(row - 1, 0), b1 = min(row + 1, c.rows - 1);
+    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
+        const uint32_t bbeg = bcs[cc * c.rows + b0], bend = bcs[cc * c.rows + b1 + 1];
         for (uint32_t j = bbeg; j < bend; j++) {
             float2 pj = bpos[j];
             float dx = pi.x - pj.x, dy = pi.y - pj.y;
@@ -595,11 +678,10 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
     float2 pi = pos[i], vi = vel[i], rpi = rp[i];
     int row, col;
     cell_of_key(c, skey[i], row, col);
-    int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
+    const int r0 = max(row - 2, 0), r1 = min(row + 2, c.rows - 1);      // 5x5 sort cells, see k_density_direct
     float fx = 0.0f, fy = 0.0f, bx = 0.0f, by = 0.0f;
-    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
-        int base = cc * c.rows;
-        uint32_t beg = cs[base + r0], end = cs[base + r1 + 1];
+    for (int cc = max(col - 2, 0); cc <= min(col + 2, c.cols - 1); cc++) {
+        const uint32_t beg = cs[cc * c.rows + r0], end = cs[cc * c.rows + r1 + 1];
         for (uint32_t j = beg; j < end; j++) {
             float2 pj = pos[j];
             float dx = pi.x - pj.x, dy = pi.y - pj.y;
@@ -613,7 +695,12 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
                 fy = fmaf(cf, dy, fy);
             }
         }
-        uint32_t bbeg = bcs[base + r0], bend = bcs[base + r1 + 1];
+    }
+    bool oob, bad;
+    cell_of(c, pi.x, pi.y, row, col, oob, bad);                          // walls: 3x3 around the CURRENT cell
+    const int b0 = max(row - 1, 0), b1 = min(row + 1, c.rows - 1);
+    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
+        const uint32_t bbeg = bcs[cc * c.rows + b0], bend = bcs[cc * c.rows + b1 + 1];
         for (uint32_t j = bbeg; j < bend; j++) {
             float2 pj = bpos[j];
             float dx = pi.x - pj.x, dy = pi.y - pj.y;
@@ -646,10 +733,10 @@ void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, i
     uint32_t *rb = consume_rebuild ? a.rebuild : nullptr;
     if (mode == DENS_RHO_EOS)
         hipLaunchKernelGGL(k_density_direct<true>, g, b, 0, st, c, a.pos, a.skey, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, rb, a.dn);
+                           a.rp, a.prs, rb, a.check, a.dn);
     else
         hipLaunchKernelGGL(k_density_direct<false>, g, b, 0, st, c, a.pos, a.skey, a.cell_start, a.bpos, a.bpsi, a.bcell_start,
-                           a.rp, a.prs, rb, a.dn);
+                           a.rp, a.prs, rb, a.check, a.dn);
 }
 
 // mode: FORCE_EVAL / FORCE_KICK / FORCE_KICK_DRIFT (the latter with the list kernels only: sph_abi.hip never asks the
@@ -890,9 +977,10 @@ __global__ __launch_bounds__(BLK) void k_metaballs(Consts c, const float2 *__res
     int row, col;
     bool oob, bad;
     cell_of(c, px, py, row, col, oob, bad);
-    int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
+    // 5x5 sort cells: a particle may be up to H + skin from where it was sorted (see drift_verdict)
+    int r0 = max(row - 2, 0), r1 = min(row + 2, c.rows - 1);
     float s = 0.0f;
-    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) {
+    for (int cc = max(col - 2, 0); cc <= min(col + 2, c.cols - 1); cc++) {
         int base = cc * c.rows;
         uint32_t beg = cs[base + r0], end = cs[base + r1 + 1];
         for (uint32_t k = beg; k < end; k++) {

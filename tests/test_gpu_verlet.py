@@ -75,7 +75,9 @@ def test_reused_lists_equal_exact_walk(sph, orc, skin, frac):
             ctx.sync()
             lists_vs_exact_walk(ctx, (frac, k))
         r1, direct = ctx.rebuild_stats()
-        assert 0 < r1 - r0 < done, (r0, r1)          # rebuilt at least once, and not every step
+        assert r1 - r0 < done, (r0, r1)              # the lists were reused (their validity: the checks above)
+        if frac <= 0.05:
+            assert r1 - r0 > 0, (r0, r1)             # a thin skin cannot survive 400 steps of a collapsing dam
         assert direct == 0
 
 
@@ -151,3 +153,29 @@ def test_fast_random_particles(sph, orc, skin):
                 lists_vs_exact_walk(ctx, (frac, k))
             got = ctx.read_particles()
             assert np.all(np.isfinite(got["x"])) and np.all(np.isfinite(got["rho"]))
+
+
+def test_coherent_motion_keeps_lists(sph, orc, oracle, skin):
+    """a block moving as a whole at 30 m/s (0.5 skin/2 per step at the default skin): the absolute criterion would
+    rebuild every other step; the relative one (per-wave displacement boxes) keeps the lists for many steps.  Results
+    against the oracle and against the exact walk as usual."""
+    skin(0.15)
+    prm, f, b = sph.scene_block((0.0, 40.0, 0.0, 6.0), 2.0, 1.5, 160, 40)
+    f["u"] = 30.0
+    p = oracle.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
+    of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()
+    oracle.psi(p, ob)
+    du, dv = oracle.eval(p, of, ob, GX, GY)
+    oracle.steps(p, of, ob, GX, GY, du, dv, 150)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        r0, _ = ctx.rebuild_stats()
+        for k in range(5):
+            ctx.step(30, GX, GY)
+            ctx.sync()
+            lists_vs_exact_walk(ctx, k)
+        got = ctx.read_particles()
+        r1, _ = ctx.rebuild_stats()
+        checks = ctx.check_stats()
+    assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-4
+    assert checks >= 140                      # the block moved more than skin/2 within two steps ...
+    assert r1 - r0 <= 40, (r0, r1)            # ... but it moved together: few rebuilds (absolute criterion: ~75)
