@@ -81,8 +81,8 @@ struct Arrays {
     // misc
     float2 *grav;       // gravity vector read by the force kernel
     uint32_t *flags;    // see FLAG_*
-    float4 *wbox;       // per wave (64 consecutive sorted particles): bounding box of displacement since the last rebuild
-    uint32_t *wnbr;     // per wave: WNBR_WORDS words = 5 x {first, last} wave whose particles may come near this wave's
+    float4 *wbox;       // per group of BOXG consecutive sorted particles: bounding box of displacement since the last rebuild
+    uint32_t *wnbr;     // per group: WNBR_WORDS words = 5 x {first, last} group whose particles may come near this group's
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
@@ -106,7 +106,12 @@ enum {
     FLAG_COUNT = 12
 };
 constexpr int TILE_WORDS = 16;           // 32-bit words per tile record
-constexpr int WNBR_WORDS = 10;           // words per wave in Arrays::wnbr
+constexpr int WNBR_WORDS = 10;           // words per box group in Arrays::wnbr
+#ifndef SPH_BOX_GROUP
+#define SPH_BOX_GROUP 64                 // consecutive sorted particles per displacement box (power of two, <= 64;
+                                         // 16 / 32 / 64 measured the same rebuild rates on the dam break: one per wave)
+#endif
+constexpr int BOXG = SPH_BOX_GROUP;
 #ifndef SPH_TILE_PARTICLES
 #define SPH_TILE_PARTICLES 256           // particles per tile (= threads per workgroup of the list kernels)
 #endif

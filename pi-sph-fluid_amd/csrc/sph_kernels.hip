@@ -86,23 +86,23 @@ void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
 //       need |u_i - u_k| > 2H + 2 skin).
 // (0) is absolute: one fast jet makes everybody rebuild.  (1) is Galilean-invariant where it matters: a coherent jet
 // keeps its lists.  The drifting kernel evaluates (0) and the cap of (1) per particle and leaves the bounding box of
-// u over each wave (64 consecutive sorted particles) in wbox; only if (0) fails, k_check evaluates the pair part of
-// (1) on the boxes of the waves k_build_list found to be within two cells of each other (conservative: boxes).
+// u over each group of BOXG consecutive sorted particles (~2 cells) in wbox; only if (0) fails, k_check evaluates the
+// pair part of (1) on the boxes of the groups k_build_list found to be within two cells of each other (conservative).
 // The direct walks (fallback tiles, variant 1, metaballs) look at 5x5 sort cells, which is exact under the cap alone.
 // Slab mode uses (0) only: the boxes of ghost waves are not known before the halo exchange.
-DEV float wave_min(float v) {
+DEV float group_min(float v) {      // over the BOXG lanes of this lane's group
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    for (int d = BOXG / 2; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
     return v;
 }
-DEV float wave_max(float v) {
+DEV float group_max(float v) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    for (int d = BOXG / 2; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
     return v;
 }
-// all 64 lanes of the wave must call this (live = the lane holds a particle); wave = global wave index (slot / 64)
+// all 64 lanes of the wave must call this (live = the lane holds a particle); slot = the lane's index in the sorted arrays
 template <bool SLAB>
-DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int wave, float4 *__restrict__ wbox,
+DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int slot, float4 *__restrict__ wbox,
                        uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild) {
     const float d2 = fmaf(ux, ux, uy * uy);
     const bool over = live && !(d2 <= c.lim2);      // true for NaN too
@@ -112,11 +112,11 @@ DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int wave,
     }
     const bool capped = live && !(d2 <= c.cap2);
     const float inf = __builtin_huge_valf();
-    const float x0 = wave_min(live ? ux : inf), y0 = wave_min(live ? uy : inf);
-    const float x1 = wave_max(live ? ux : -inf), y1 = wave_max(live ? uy : -inf);
-    const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped), any_live = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && any_live != 0ull) {
-        wbox[wave] = make_float4(x0, y0, x1, y1);
+    const float x0 = group_min(live ? ux : inf), y0 = group_min(live ? uy : inf);
+    const float x1 = group_max(live ? ux : -inf), y1 = group_max(live ? uy : -inf);
+    const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped);
+    if (live && (threadIdx.x & (BOXG - 1)) == 0) wbox[slot / BOXG] = make_float4(x0, y0, x1, y1);   // live lanes are a prefix
+    if ((threadIdx.x & 63) == 0) {
         if (any_over != 0ull) *check = 1u;
         if (any_cap != 0ull) *rebuild = 1u;
     }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
         ux = p.x - r.x;
         uy = p.y - r.y;
     }
-    drift_verdict<SLAB>(c, ux, uy, live, t >> 6, wbox, check, rebuild);
+    drift_verdict<SLAB>(c, ux, uy, live, t, wbox, check, rebuild);
 }
 
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab) {
@@ -244,14 +244,14 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
     }
 }
 
-// the pair part of criterion (1): one thread per wave, against every wave k_build_list listed for it
+// the pair part of criterion (1): one thread per box group, against every group k_build_list listed for it
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                                                const uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild,
                                                uint32_t *__restrict__ flags, const uint32_t *__restrict__ dn) {
     if (*check == 0u) return;
     const int w = blockIdx.x * BLK + threadIdx.x;
     if (w == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
-    const int nw = ((int)dn[0] + 63) >> 6;
+    const int nw = ((int)dn[0] + BOXG - 1) / BOXG;
     if (w >= nw) return;
     const float4 b = wbox[w];
     const uint32_t *nb = wnbr + (size_t)w * WNBR_WORDS;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
 }
 void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     if (cap <= 0) return;
-    const int nw = (cap + 63) / 64;
+    const int nw = (cap + BOXG - 1) / BOXG;
     hipLaunchKernelGGL(k_check, dim3((nw + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.check, a.rebuild, a.flags, a.dn);
 }
 
