@@ -38,6 +38,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner with printf when
+# its first communicator is created), so the process's stdout is pointed at stderr for the whole run and the result
+# line goes to the original descriptor.
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
+
+
 def run_single(sph, name, steps, warmup, profile_steps=20):
     """K timed steps of one scene on device 0; returns a result dict."""
     prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
@@ -136,6 +156,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary cfg1 measurement")
     args = ap.parse_args()
+    quiet_stdout()
 
     sph = importlib.import_module("pi-sph-fluid_amd")
     if not (os.path.exists(sph.LIB_HIP) and os.path.exists(sph.LIB_HOST)):
@@ -144,7 +165,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("SPH_FORCE_SLAB") == "1":
         from bench_slab import run_slabs          # one process per GPU over RCCL (torch.distributed)
-        run_slabs(sph, args)
+        run_slabs(sph, args, emit)
         return
 
     res = run_single(sph, args.workload, args.steps, args.warmup)
@@ -180,7 +201,7 @@ def main():
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sph, args.workload)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 if __name__ == "__main__":

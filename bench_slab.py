@@ -50,7 +50,7 @@ class HostStagedTransport:
             self.slab.copy_in(1, self.rr.numpy().view(np.uint32))
 
 
-def run_slabs(sph, args):
+def run_slabs(sph, args, emit):
     import torch
     import torch.distributed as dist
 
@@ -118,7 +118,7 @@ def run_slabs(sph, args):
                          "frac": round(sph.STEP_ALGO_BYTES * n_total * steps_per_s / 1e9 / world / HBM_PEAK_GBS, 4),
                          "traffic": None},
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     dist.barrier()
     dist.destroy_process_group()
     slab.close()

@@ -150,7 +150,7 @@ size_t padded_items(const Consts &c) {
     return (n_items + SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
 }
 
-bool fused(const sph_ctx *ctx) { return !ctx->slab && ctx->variant == 0; }
+bool fused(const sph_ctx *ctx) { return ctx->variant == 0; }
 
 // What a step launches after its kick/drift (SPH_K_* order; ev != nullptr records an event before each): the rebuild
 // kernels (no-ops unless requested), density + EOS, force + kick.  With the list kernels the force pass also
@@ -729,7 +729,16 @@ int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     launch_set_gravity(st, ctx->a, gx, gy);
-    launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, true);      // owned range; raises the rebuild word when lists may be stale
+    // kick 1/2 + drift of the owned range: done by the previous step's force pass (swap the sets; the ghost entries of
+    // the swapped-in set are refreshed by this step's halo exchange) or by the stand-alone kernel; either has raised
+    // the rebuild word if the lists may be stale
+    if (fused(ctx) && ctx->primed) {
+        std::swap(ctx->a.pos, ctx->a.pos2);
+        std::swap(ctx->a.vel, ctx->a.vel2);
+    } else {
+        launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, true);
+    }
+    ctx->primed = fused(ctx);
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_phase = 1;
     return SPH_OK;
@@ -760,7 +769,7 @@ int sph_slab_step_end(sph_ctx *ctx) {
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     launch_unpack_update(st, ctx->c, ctx->a);                   // other steps only
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true);
-    launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK, ctx->variant);
+    launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_phase = 0;
     return SPH_OK;

@@ -100,13 +100,13 @@ DEV float group_max(float v) {
     for (int d = BOXG / 2; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
     return v;
 }
-// all 64 lanes of the wave must call this (live = the lane holds a particle); slot = the lane's index in the sorted arrays
-template <bool SLAB>
-DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int slot, float4 *__restrict__ wbox,
+// all 64 lanes of the wave must call this (live = the lane holds a particle this rank integrates); slot = the lane's
+// index in the sorted arrays; slab = wave-uniform: a slab context (criterion (0) only)
+DEV void drift_verdict(const Consts &c, bool slab, float ux, float uy, bool live, int slot, float4 *__restrict__ wbox,
                        uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild) {
     const float d2 = fmaf(ux, ux, uy * uy);
     const bool over = live && !(d2 <= c.lim2);      // true for NaN too
-    if (SLAB) {
+    if (slab) {
         if (__ballot(over) != 0ull && (threadIdx.x & 63) == 0) *rebuild = 1u;
         return;
     }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
         ux = p.x - r.x;
         uy = p.y - r.y;
     }
-    drift_verdict<SLAB>(c, ux, uy, live, t, wbox, check, rebuild);
+    drift_verdict(c, SLAB, ux, uy, live, t, wbox, check, rebuild);
 }
 
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab) {

@@ -76,3 +76,19 @@ def boundary_particles(orc_mod, xy, psi=None, rho0=1000.0):
 
 def bits_equal(a, b):
     return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+_block_cache = {}
+
+
+def oracle_block_300(oracle, orc_mod, fluid, boundary_psi, box):
+    """the oracle's state after 300 steps of the 14 400-particle dam break from the lattice (shared by several GPU tests:
+    a few seconds of CPU each time otherwise)."""
+    key = (len(fluid), tuple(box))
+    if key not in _block_cache:
+        p = oracle.params(box)
+        of = fluid.copy()
+        du, dv = oracle.eval(p, of, boundary_psi, GX, GY, threads=8)
+        oracle.steps(p, of, boundary_psi, GX, GY, du, dv, 300, threads=8)
+        _block_cache[key] = of
+    return _block_cache[key].copy()

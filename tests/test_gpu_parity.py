@@ -20,7 +20,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import B_EOS, GOLDEN, GX, GY, boundary_particles, load_golden, particles
+from conftest import B_EOS, GOLDEN, GX, GY, boundary_particles, load_golden, oracle_block_300, particles
 
 MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
 
@@ -152,11 +152,8 @@ def test_block_trajectory_vs_oracle(sph, orc, oracle, variant):
     xy = g["fluid_xy0"]
     state = np.concatenate([xy, np.zeros_like(xy)], 1)
     prm, f, ctx = make_ctx(sph, orc, box, state, g["boundary_xy"], variant)
-    p = oracle.params(box)
     b = boundary_particles(orc, g["boundary_xy"], g["psi"])
-    of = f.copy()
-    du, dv = oracle.eval(p, of, b, GX, GY)
-    oracle.steps(p, of, b, GX, GY, du, dv, 300)
+    of = oracle_block_300(oracle, orc, f, b, box)
     with ctx:
         ctx.step(300, GX, GY)
         ctx.sync()
@@ -297,7 +294,7 @@ def test_time_varying_gravity(sph, orc, oracle):
             t += prm.dt
             gx, gy = grav.sample(t)
             ctx.step(1, gx, gy)
-            oracle.steps(p, of, ob, gx, gy, du, dv, 1)
+            oracle.steps(p, of, ob, gx, gy, du, dv, 1, threads=8)
         ctx.sync()
         got = ctx.read_particles()
         assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-5
@@ -371,7 +368,7 @@ def test_non_default_parameters(sph, orc, oracle, r, c_sound, alpha, k1):
         ctx.step(40, GX, GY)
         ctx.sync()
         got = ctx.read_particles()
-    oracle.steps(p, of, ob, GX, GY, du, dv, 40)
+    oracle.steps(p, of, ob, GX, GY, du, dv, 40, threads=8)
     assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-5
 
 

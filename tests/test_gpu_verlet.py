@@ -10,7 +10,7 @@ inside the support and listed pairs beyond it contribute exactly 0.  These tests
 import numpy as np
 import pytest
 
-from conftest import GX, GY, boundary_particles, load_golden, particles
+from conftest import GX, GY, boundary_particles, load_golden, oracle_block_300, particles
 
 pytestmark = pytest.mark.gpu
 
@@ -101,11 +101,8 @@ def test_trajectory_does_not_depend_on_skin(sph, orc, oracle, skin, frac):
     skin(frac)
     prm, f, b, g = block_scene(sph, orc)
     box = tuple(g["box"])
-    p = oracle.params(box)
     ob = boundary_particles(orc, g["boundary_xy"], g["psi"])
-    of = f.copy()
-    du, dv = oracle.eval(p, of, ob, GX, GY)
-    oracle.steps(p, of, ob, GX, GY, du, dv, 300)
+    of = oracle_block_300(oracle, orc, f, ob, box)
     with sph.Context(prm, f, b, GX, GY) as ctx:
         ctx.step(300, GX, GY)
         ctx.sync()
@@ -166,7 +163,7 @@ def test_coherent_motion_keeps_lists(sph, orc, oracle, skin):
     of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()
     oracle.psi(p, ob)
     du, dv = oracle.eval(p, of, ob, GX, GY)
-    oracle.steps(p, of, ob, GX, GY, du, dv, 150)
+    oracle.steps(p, of, ob, GX, GY, du, dv, 150, threads=8)
     with sph.Context(prm, f, b, GX, GY) as ctx:
         r0, _ = ctx.rebuild_stats()
         for k in range(5):
