@@ -739,6 +739,7 @@ int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
         launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, true);
     }
     ctx->primed = fused(ctx);
+    launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2 somewhere: compare the boxes; may raise the rebuild word
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_phase = 1;
     return SPH_OK;

@@ -89,7 +89,9 @@ void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
 // u over each group of BOXG consecutive sorted particles (~2 cells) in wbox; only if (0) fails, k_check evaluates the
 // pair part of (1) on the boxes of the groups k_build_list found to be within two cells of each other (conservative).
 // The direct walks (fallback tiles, variant 1, metaballs) look at 5x5 sort cells, which is exact under the cap alone.
-// Slab mode uses (0) only: the boxes of ghost waves are not known before the halo exchange.
+// Slab mode: a ghost's box is not known before the halo exchange, so groups that can meet ghosts (their ranges touch
+// the ghost slots) must satisfy (0); a pair across an interface has both partners in such groups, each held to
+// skin/2 by its owner.  Everybody else is compared as on a single GPU (all the boxes involved are owned ones).
 DEV float group_min(float v) {      // over the BOXG lanes of this lane's group
 #pragma unroll
     for (int d = BOXG / 2; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
@@ -100,22 +102,21 @@ DEV float group_max(float v) {
     for (int d = BOXG / 2; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
     return v;
 }
-// all 64 lanes of the wave must call this (live = the lane holds a particle this rank integrates); slot = the lane's
-// index in the sorted arrays; slab = wave-uniform: a slab context (criterion (0) only)
-DEV void drift_verdict(const Consts &c, bool slab, float ux, float uy, bool live, int slot, float4 *__restrict__ wbox,
+// all 64 lanes of the wave must call this (live = the lane holds a particle this rank integrates: in slab mode the
+// boxes cover the owned particles only); slot = the lane's index in the sorted arrays
+DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int slot, float4 *__restrict__ wbox,
                        uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild) {
     const float d2 = fmaf(ux, ux, uy * uy);
     const bool over = live && !(d2 <= c.lim2);      // true for NaN too
-    if (slab) {
-        if (__ballot(over) != 0ull && (threadIdx.x & 63) == 0) *rebuild = 1u;
-        return;
-    }
     const bool capped = live && !(d2 <= c.cap2);
     const float inf = __builtin_huge_valf();
     const float x0 = group_min(live ? ux : inf), y0 = group_min(live ? uy : inf);
     const float x1 = group_max(live ? ux : -inf), y1 = group_max(live ? uy : -inf);
     const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped);
-    if (live && (threadIdx.x & (BOXG - 1)) == 0) wbox[slot / BOXG] = make_float4(x0, y0, x1, y1);   // live lanes are a prefix
+    // the first live lane of each group writes its box (slab mode: the owned range may begin or end inside a group)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long group = (BOXG == 64 ? ~0ull : ((1ull << (BOXG & 63)) - 1ull) << (lane & ~(BOXG - 1))) & __ballot(live);
+    if (group != 0ull && lane == (int)__builtin_ctzll(group)) wbox[slot / BOXG] = make_float4(x0, y0, x1, y1);
     if ((threadIdx.x & 63) == 0) {
         if (any_over != 0ull) *check = 1u;
         if (any_cap != 0ull) *rebuild = 1u;
@@ -131,12 +132,12 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
                                                     float4 *__restrict__ wbox, uint32_t *__restrict__ check,
                                                     uint32_t *__restrict__ rebuild, const uint32_t *__restrict__ dn) {
     // slab mode: only the OWNED range of the sorted arrays moves (cell_start of the last rebuild); the ghosts are
-    // refreshed from their owners by the halo exchange of this step
-    const int src0 = SLAB ? (int)cs[c.ghost * c.rows] : 0;
-    const int n = SLAB ? (int)cs[(c.ghost + c.owned) * c.rows] - src0 : (int)dn[0];
-    const int t = blockIdx.x * BLK + threadIdx.x;
-    const bool live = t < n;
-    const int i = src0 + (live ? t : 0);
+    // refreshed from their owners by the halo exchange of this step.  One thread per array slot, so that a wave is
+    // one box group here as in the force pass.
+    const int own_lo = SLAB ? (int)cs[c.ghost * c.rows] : 0;
+    const int own_hi = SLAB ? (int)cs[(c.ghost + c.owned) * c.rows] : (int)dn[0];
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    const bool live = i >= own_lo && i < own_hi;
     float ux = 0.0f, uy = 0.0f;
     if (live) {
         const float2 a = acc[i], r = pos_ref[i];
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
         ux = p.x - r.x;
         uy = p.y - r.y;
     }
-    drift_verdict(c, SLAB, ux, uy, live, t, wbox, check, rebuild);
+    drift_verdict(c, ux, uy, live, i, wbox, check, rebuild);
 }
 
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab) {
@@ -246,23 +247,37 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
 
 // the pair part of criterion (1): one thread per box group, against every group k_build_list listed for it
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
-                                               const uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild,
-                                               uint32_t *__restrict__ flags, const uint32_t *__restrict__ dn) {
+                                               const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
+                                               uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
+                                               const uint32_t *__restrict__ dn) {
     if (*check == 0u) return;
     const int w = blockIdx.x * BLK + threadIdx.x;
     if (w == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
-    const int nw = ((int)dn[0] + BOXG - 1) / BOXG;
-    if (w >= nw) return;
+    const int n = (int)dn[0];
+    // the slots this rank integrates (single GPU: all of them)
+    const int own_lo = c.ghost ? (int)cs[c.ghost * c.rows] : 0, own_hi = c.ghost ? (int)cs[(c.ghost + c.owned) * c.rows] : n;
+    if (w * BOXG >= own_hi || (w + 1) * BOXG <= own_lo) return;      // no owned particle in this group: no box
     const float4 b = wbox[w];
     const uint32_t *nb = wnbr + (size_t)w * WNBR_WORDS;
-    bool bad = false;
+    bool meets_ghosts = false;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const uint32_t first = nb[2 * k], last = nb[2 * k + 1];
-        for (uint32_t o = first; o <= last && o != 0xffffffffu; o++) {      // first > last: nobody in that column
-            const float4 q = wbox[o];
-            const float rx = fmaxf(b.z - q.x, q.z - b.x), ry = fmaxf(b.w - q.y, q.w - b.y);
-            bad |= !(fmaf(rx, rx, ry * ry) <= c.skin2);
+        if (first <= last) meets_ghosts |= (int)(first * BOXG) < own_lo || (int)((last + 1u) * BOXG) > own_hi;
+    }
+    bool bad = false;
+    if (meets_ghosts) {
+        const float mx = fmaxf(fabsf(b.x), fabsf(b.z)), my = fmaxf(fabsf(b.y), fabsf(b.w));
+        bad = !(fmaf(mx, mx, my * my) <= c.lim2);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint32_t first = nb[2 * k], last = nb[2 * k + 1];
+            for (uint32_t o = first; o <= last && o != 0xffffffffu; o++) {      // first > last: nobody in that column
+                const float4 q = wbox[o];
+                const float rx = fmaxf(b.z - q.x, q.z - b.x), ry = fmaxf(b.w - q.y, q.w - b.y);
+                bad |= !(fmaf(rx, rx, ry * ry) <= c.skin2);
+            }
         }
     }
     if (bad) *rebuild = 1u;
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
 void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     if (cap <= 0) return;
     const int nw = (cap + BOXG - 1) / BOXG;
-    hipLaunchKernelGGL(k_check, dim3((nw + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.check, a.rebuild, a.flags, a.dn);
+    hipLaunchKernelGGL(k_check, dim3((nw + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check, a.rebuild, a.flags, a.dn);
 }
 
 #define KH_ARGS(vsrc) c, a.pos, a.id, vsrc, a.cell_start, a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1]
