@@ -750,9 +750,8 @@ int sph_slab_step_pack(sph_ctx *ctx) {
     if (!ctx->slab || ctx->slab_phase != 1) return fail(ctx, SPH_E_STATE, "sph_slab_step_pack without sph_slab_step_begin");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    for (int k = 0; k < 2; k++) HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, HALO_HDR * sizeof(uint32_t), st));
-    launch_key_owned_pack(st, ctx->c, ctx->a, ctx->cap);        // rebuild step: full records (ghosts + migration)
-    launch_pack_update(st, ctx->c, ctx->a);                     // other steps: x, y, u, v of the interface columns
+    // rebuild step: full records (ghosts + migration); other steps: x, y, u, v of the interface columns
+    launch_halo_out(st, ctx->c, ctx->a, ctx->cap);
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_phase = 2;
     return SPH_OK;
@@ -763,12 +762,11 @@ int sph_slab_step_end(sph_ctx *ctx) {
     if (!ctx->slab || ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_pack");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    launch_ingest(st, ctx->c, ctx->a, ctx->cap);                // rebuild step only (like the next four)
+    launch_halo_in(st, ctx->c, ctx->a, ctx->cap);               // rebuild step: ingest (then the next four); else ghost update
     launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     launch_canon(st, ctx->c, ctx->a);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
-    launch_unpack_update(st, ctx->c, ctx->a);                   // other steps only
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true);
     launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     HIPCHK(ctx, hipGetLastError());

@@ -132,17 +132,15 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy);
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
 // first half kick + drift in place (:615-624; slab mode: the owned range); requests a rebuild when the lists may be stale
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab);
-// slab mode, rebuild step: keys + histogram of the owned range into the staging arrays + full-record halo pack
-void launch_key_owned_pack(hipStream_t st, const Consts &c, const Arrays &a, int cap);
-// slab mode, other steps: position/velocity updates of the interface columns (no-ops on a rebuild step)
-void launch_pack_update(hipStream_t st, const Consts &c, const Arrays &a);
-void launch_unpack_update(hipStream_t st, const Consts &c, const Arrays &a);
+// slab mode: fill the send buffers — rebuild step: keys + histogram of the owned range into the staging arrays + full
+// records; other steps: position/velocity updates of the interface columns
+void launch_halo_out(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// slab mode: consume the receive buffers — rebuild step: records join the staging arrays; other steps: ghosts updated in place
+void launch_halo_in(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap);
 // slab mode, rebuild step: canonical (by id) particle order inside the cells of the interface columns
 void launch_canon(hipStream_t st, const Consts &c, const Arrays &a);
 // rebuild: keys + histogram of (pos, vsrc, id) as they are, into the staging arrays
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc);
-// slab mode: append the received halo records to the staging arrays, then dn[0] = owned + received
-void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap);
 // slab mode: owned particles (sorted order) -> compact AoS + ids; count left in dn[1]... see sph_abi.hip
 void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int cap, sph_particle *out_dev, uint32_t *ids_dev,
                          float *du, float *dv);

@@ -181,14 +181,11 @@ DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, ui
 }
 
 template <bool SLAB>
-__global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__restrict__ pos, const uint32_t *__restrict__ id,
-                                                  const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs,
-                                                  float2 *__restrict__ velk, float4 *__restrict__ pk,
-                                                  uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
-                                                  uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
-                                                  const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
-                                                  uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r) {
-    if (*rebuild == 0u) return;      // rebuild kernel
+DEV void key_hist_body(const Consts &c, const float2 *__restrict__ pos, const uint32_t *__restrict__ id,
+                       const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs, float2 *__restrict__ velk,
+                       float4 *__restrict__ pk, uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
+                       uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags, uint32_t *__restrict__ dn,
+                       uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r) {
     const int t = blockIdx.x * BLK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int src0 = 0, n;
@@ -245,11 +242,26 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
     }
 }
 
+// single GPU, init, upload: keys + histogram of entries 0..dn[0]-1 as they are
+__global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__restrict__ pos, const uint32_t *__restrict__ id,
+                                                  const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs,
+                                                  float2 *__restrict__ velk, float4 *__restrict__ pk,
+                                                  uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
+                                                  uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
+                                                  const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn) {
+    if (*rebuild == 0u) return;      // rebuild kernel
+    key_hist_body<false>(c, pos, id, vsrc, cs, velk, pk, slot, count, dirty, flags, dn, nullptr, nullptr);
+}
+
 // the pair part of criterion (1): one thread per box group, against every group k_build_list listed for it
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                                                const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
                                                uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
-                                               const uint32_t *__restrict__ dn) {
+                                               const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
+                                               uint32_t *__restrict__ send_r) {
+    // slab mode: this is the first kernel of a step; it also clears the headers of the send buffers (count, kind) for
+    // the pack that follows the reduction of the rebuild word
+    if (send_l && blockIdx.x == 0 && threadIdx.x < 2 * HALO_HDR) (threadIdx.x < HALO_HDR ? send_l : send_r)[threadIdx.x & (HALO_HDR - 1)] = 0u;
     if (*check == 0u) return;
     const int w = blockIdx.x * BLK + threadIdx.x;
     if (w == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
@@ -285,19 +297,14 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
 void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     if (cap <= 0) return;
     const int nw = (cap + BOXG - 1) / BOXG;
-    hipLaunchKernelGGL(k_check, dim3((nw + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check, a.rebuild, a.flags, a.dn);
+    hipLaunchKernelGGL(k_check, dim3((nw + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check, a.rebuild, a.flags, a.dn, a.send[0], a.send[1]);
 }
 
-#define KH_ARGS(vsrc) c, a.pos, a.id, vsrc, a.cell_start, a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1]
-void launch_key_owned_pack(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
-    if (cap <= 0) return;
-    hipLaunchKernelGGL((k_key_hist<true>), dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, KH_ARGS(a.vel));
-}
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc) {
     if (cap <= 0) return;
-    hipLaunchKernelGGL((k_key_hist<false>), dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, KH_ARGS(vsrc));
+    hipLaunchKernelGGL(k_key_hist, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.id, vsrc, a.cell_start, a.velk,
+                       a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn);
 }
-#undef KH_ARGS
 
 // ------------------------------------------------------------------------------------------
 // slab mode, steps WITHOUT a rebuild: the local particle set and its order are unchanged, so a ghost only needs its
@@ -305,17 +312,13 @@ void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, 
 // particle id, k_canon), so the owner's two outermost owned columns and the neighbour's two ghost columns are the
 // SAME sequence of particles: the update is a plain copy of a contiguous range, 16 bytes per particle.
 // Buffer header: {count, kind, 0, 0}, kind 0 = full records (rebuild step), 1 = update.
-__global__ __launch_bounds__(BLK) void k_pack_update(Consts c, const float2 *__restrict__ pos, const float2 *__restrict__ vel,
-                                                     const uint32_t *__restrict__ cs, const uint32_t *__restrict__ rebuild,
-                                                     uint32_t *__restrict__ flags, uint32_t *__restrict__ send_l,
-                                                     uint32_t *__restrict__ send_r) {
-    if (*rebuild != 0u) return;      // a rebuild step sends full records instead (k_key_hist<true>)
-    const int side = blockIdx.y;
+DEV void pack_update_body(const Consts &c, int side, int t, const float2 *__restrict__ pos, const float2 *__restrict__ vel,
+                          const uint32_t *__restrict__ cs, uint32_t *__restrict__ flags, uint32_t *__restrict__ send_l,
+                          uint32_t *__restrict__ send_r) {
     if (side == 0 ? !c.has_left : !c.has_right) return;
     const int col0 = side == 0 ? c.ghost : c.ghost + c.owned - 2;
     const int beg = (int)cs[col0 * c.rows], n = (int)cs[(col0 + 2) * c.rows] - beg;
     uint32_t *buf = side == 0 ? send_l : send_r;
-    const int t = blockIdx.x * BLK + threadIdx.x;
     if (t == 0) {
         buf[0] = (uint32_t)min(n, c.halo_cap);
         buf[1] = 1u;
@@ -326,17 +329,13 @@ __global__ __launch_bounds__(BLK) void k_pack_update(Consts c, const float2 *__r
     reinterpret_cast<float4 *>(buf + HALO_HDR)[t] = make_float4(p.x, p.y, v.x, v.y);
 }
 
-__global__ __launch_bounds__(BLK) void k_unpack_update(Consts c, float2 *__restrict__ pos, float2 *__restrict__ vel,
-                                                       const uint32_t *__restrict__ cs, const uint32_t *__restrict__ rebuild,
-                                                       uint32_t *__restrict__ flags, const uint32_t *__restrict__ recv_l,
-                                                       const uint32_t *__restrict__ recv_r) {
-    if (*rebuild != 0u) return;
-    const int side = blockIdx.y;
+DEV void unpack_update_body(const Consts &c, int side, int t, float2 *__restrict__ pos, float2 *__restrict__ vel,
+                            const uint32_t *__restrict__ cs, uint32_t *__restrict__ flags, const uint32_t *__restrict__ recv_l,
+                            const uint32_t *__restrict__ recv_r) {
     if (side == 0 ? !c.has_left : !c.has_right) return;
     const int col0 = side == 0 ? 0 : c.ghost + c.owned;
     const int beg = (int)cs[col0 * c.rows], n = (int)cs[(col0 + c.ghost) * c.rows] - beg;
     const uint32_t *buf = side == 0 ? recv_l : recv_r;
-    const int t = blockIdx.x * BLK + threadIdx.x;
     // the neighbour must have sent an update of exactly my ghost range (same rebuild step, same canonical order)
     if (t == 0 && (buf[0] != (uint32_t)n || buf[1] != 1u)) atomicAdd(&flags[FLAG_MISMATCH], 1u);
     if (t >= n || t >= (int)buf[0]) return;
@@ -345,15 +344,32 @@ __global__ __launch_bounds__(BLK) void k_unpack_update(Consts c, float2 *__restr
     vel[beg + t] = make_float2(q.z, q.w);
 }
 
-void launch_pack_update(hipStream_t st, const Consts &c, const Arrays &a) {
-    if (c.halo_cap <= 0) return;
-    hipLaunchKernelGGL(k_pack_update, dim3((c.halo_cap + BLK - 1) / BLK, 2), dim3(BLK), 0, st, c, a.pos, a.vel, a.cell_start,
-                       a.rebuild, a.flags, a.send[0], a.send[1]);
+// What a slab sends in this step, one launch: on a rebuild step (the reduced word is set) keys + histogram of the
+// owned range with the full-record halo pack; otherwise the update pack.  Grid: max(particle blocks, 2 x halo blocks);
+// the send headers were zeroed by k_check at the start of the step.
+__global__ __launch_bounds__(BLK) void k_halo_out(Consts c, const float2 *__restrict__ pos, const uint32_t *__restrict__ id,
+                                                  const float2 *__restrict__ vel, const uint32_t *__restrict__ cs,
+                                                  float2 *__restrict__ velk, float4 *__restrict__ pk,
+                                                  uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
+                                                  uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
+                                                  const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
+                                                  uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r,
+                                                  int part_blocks, int halo_blocks) {
+    if (*rebuild != 0u) {
+        if ((int)blockIdx.x < part_blocks)
+            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r);
+    } else if ((int)blockIdx.x < 2 * halo_blocks) {
+        const int side = (int)blockIdx.x / halo_blocks;
+        pack_update_body(c, side, ((int)blockIdx.x - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, send_l, send_r);
+    }
 }
-void launch_unpack_update(hipStream_t st, const Consts &c, const Arrays &a) {
-    if (c.halo_cap <= 0) return;
-    hipLaunchKernelGGL(k_unpack_update, dim3((c.halo_cap + BLK - 1) / BLK, 2), dim3(BLK), 0, st, c, a.pos, a.vel, a.cell_start,
-                       a.rebuild, a.flags, a.recv[0], a.recv[1]);
+
+void launch_halo_out(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+    if (cap <= 0) return;
+    const int part_blocks = (cap + BLK - 1) / BLK, halo_blocks = (c.halo_cap + BLK - 1) / BLK;
+    const int grid = part_blocks > 2 * halo_blocks ? part_blocks : 2 * halo_blocks;
+    hipLaunchKernelGGL(k_halo_out, dim3(grid), dim3(BLK), 0, st, c, a.pos, a.id, a.vel, a.cell_start, a.velk, a.pk, a.slot,
+                       a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1], part_blocks, halo_blocks);
 }
 
 // slab mode, rebuild step, after the scatter: put every cell of the interface columns (two ghost + two owned columns
@@ -393,13 +409,10 @@ void launch_canon(hipStream_t st, const Consts &c, const Arrays &a) {
 }
 
 // slab mode: the records received from the two neighbours join the staging arrays behind the owned particles
-__global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__restrict__ recv_l,
-                                                const uint32_t *__restrict__ recv_r, float2 *__restrict__ velk,
-                                                float4 *__restrict__ pk, uint32_t *__restrict__ slot,
-                                                uint32_t *__restrict__ count, uint32_t *__restrict__ dirty,
-                                                uint32_t *__restrict__ flags, const uint32_t *__restrict__ rebuild,
-                                                uint32_t *__restrict__ dn, int stage_cap) {
-    if (*rebuild == 0u) return;      // rebuild kernel (other steps: k_unpack_update)
+DEV void ingest_body(const Consts &c, const uint32_t *__restrict__ recv_l, const uint32_t *__restrict__ recv_r,
+                     float2 *__restrict__ velk, float4 *__restrict__ pk, uint32_t *__restrict__ slot,
+                     uint32_t *__restrict__ count, uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
+                     uint32_t *__restrict__ dn, int stage_cap) {
     const int n_own = (int)dn[1];
     const int nl = c.has_left ? min((int)recv_l[0], c.halo_cap) : 0;
     const int nr = c.has_right ? min((int)recv_r[0], c.halo_cap) : 0;
@@ -429,10 +442,27 @@ __global__ __launch_bounds__(BLK) void k_ingest(Consts c, const uint32_t *__rest
     else if (oob) atomicAdd(&flags[FLAG_OOB], 1u);
 }
 
-void launch_ingest(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap) {
-    const int work = 2 * c.halo_cap;
-    hipLaunchKernelGGL(k_ingest, dim3((work + BLK - 1) / BLK > 0 ? (work + BLK - 1) / BLK : 1), dim3(BLK), 0, st, c, a.recv[0],
-                       a.recv[1], a.velk, a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, stage_cap);
+// What a slab does with what it received, one launch: on a rebuild step the records join the staging arrays behind
+// the owned particles (then dn[0] = owned + received); otherwise the updates overwrite the ghost ranges in place.
+__global__ __launch_bounds__(BLK) void k_halo_in(Consts c, const uint32_t *__restrict__ recv_l,
+                                                 const uint32_t *__restrict__ recv_r, float2 *__restrict__ velk,
+                                                 float4 *__restrict__ pk, uint32_t *__restrict__ slot,
+                                                 uint32_t *__restrict__ count, uint32_t *__restrict__ dirty,
+                                                 uint32_t *__restrict__ flags, const uint32_t *__restrict__ rebuild,
+                                                 uint32_t *__restrict__ dn, int stage_cap, float2 *__restrict__ pos,
+                                                 float2 *__restrict__ vel, const uint32_t *__restrict__ cs, int halo_blocks) {
+    if (*rebuild != 0u) {
+        ingest_body(c, recv_l, recv_r, velk, pk, slot, count, dirty, flags, dn, stage_cap);
+    } else {
+        const int side = (int)blockIdx.x / halo_blocks;
+        unpack_update_body(c, side, ((int)blockIdx.x - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, recv_l, recv_r);
+    }
+}
+
+void launch_halo_in(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap) {
+    const int halo_blocks = (c.halo_cap + BLK - 1) / BLK > 0 ? (c.halo_cap + BLK - 1) / BLK : 1;
+    hipLaunchKernelGGL(k_halo_in, dim3(2 * halo_blocks), dim3(BLK), 0, st, c, a.recv[0], a.recv[1], a.velk, a.pk, a.slot,
+                       a.count, a.dirty, a.flags, a.rebuild, a.dn, stage_cap, a.pos, a.vel, a.cell_start, halo_blocks);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -120,3 +120,27 @@ def test_create_argument_errors_and_no_cpu_fallback(sph):
         assert e.value.code == sph.SPH_E_HIP
     assert L.sph_error_string(sph.SPH_E_HIP).decode().startswith("HIP failure")
     assert L.sph_step(None, 0.0, 0.0, 1) == sph.SPH_E_ARG
+
+
+def test_skin_setting_and_device_cell_are_host_only(sph):
+    """the skin (neighbour-structure reuse) is process-wide host state of the C ABI; slab hosts bin with 2H + skin."""
+    L = sph.hip_lib()
+    old = sph.default_skin()
+    try:
+        assert 0.0 <= old <= 1.0
+        prm = sph.default_params()
+        two_h = np.float32(2) * np.float32(prm.h)
+        for frac in (0.0, 0.1, 0.4):
+            sph.set_default_skin(frac)
+            assert abs(sph.default_skin() - frac) < 1e-7
+            cell = np.float32(L.sph_device_cell(C.byref(prm)))
+            assert abs(cell - two_h * (1 + np.float32(frac))) <= 2e-7
+            assert sph.slab.device_cell(prm) == cell
+            # the slab partitioner bins with that cell
+            cols = sph.slab.grid_columns(prm)
+            assert cols == int((np.float32(prm.x_max) - np.float32(prm.x_min)) / cell) + 1
+        with pytest.raises(sph.SphError):
+            sph.set_default_skin(1.5)
+        assert L.sph_set_default_skin(C.c_float(-0.1)) == sph.SPH_E_ARG
+    finally:
+        sph.set_default_skin(old)
