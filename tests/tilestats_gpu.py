@@ -27,7 +27,7 @@ for s in range(3):
     lo = np.clip(lo, 0, ncell - 1); hi = np.clip(hi, 0, ncell - 1)
     tot += np.where(ok, cs[hi + 1] - cs[lo], 0)
 span = khi - klo
-print("blocks", nb, "total: mean %.0f p50 %d p90 %d p99 %d max %d ; >960: %.1f%%  >1024: %.1f%%" % (
+print("blocks", nb, "total: mean %.0f p50 %d p90 %d p99 %d max %d ; >1152: %.1f%%  >1280: %.1f%%" % (
     tot.mean(), np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), 100 * np.mean(tot > 1152), 100 * np.mean(tot > 1280)))
 print("span: mean %.0f p50 %d p90 %d p99 %d max %d ; >250: %.1f%%" % (span.mean(), np.percentile(span, 50), np.percentile(span, 90), np.percentile(span, 99), span.max(), 100 * np.mean(span > 250)))
 cnt = np.diff(cs); occ = cnt[cnt > 0]
