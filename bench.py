@@ -198,6 +198,18 @@ def main():
                         "kernel_ms": {k: round(v, 5) for k, v in r1["kernel_ms"].items()},
                         "neighbour_rebuilds_per_step": round(r1["timed_rebuilds_per_step"], 4),
                         "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r1["n_fluid"] * r1["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)}]
+    if not args.no_also and args.workload == "cfg2":
+        # the same scene once the flow is developed (splashes, |v| ~ 25 m/s): the neighbour structure is rebuilt three
+        # times as often as in the headline window
+        late_warm = 4000
+        r2 = run_single(sph, "cfg2", max(args.steps, 1), late_warm)
+        log("also:", json.dumps(r2))
+        out["also"].append({"workload": "cfg2, developed flow: steps %d-%d of the same run" % (late_warm, late_warm + args.steps),
+                            "value": round(r2["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
+                            "timesteps_per_s": round(r2["steps_per_s"], 2), "ms_per_step": round(r2["ms_per_step"], 5),
+                            "neighbour_rebuilds_per_step": round(r2["timed_rebuilds_per_step"], 4),
+                            "max_speed": round(r2["max_speed"], 2),
+                            "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r2["n_fluid"] * r2["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)})
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sph, args.workload)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
