@@ -94,7 +94,8 @@ int  sph_device_count(void);
 
 /* Replaces the init sequence :594-607 (alloc_neighbors_context x2, update_neighbors_context,
  * calculate_boundary_pseudomass, first calculate_density/_particle_pressure/_accelerations).
- * Copies fluid[0..n_fluid) (x,y,u,v; m must equal rho0*vol) and boundary[0..n_boundary) (x,y),
+ * Copies fluid[0..n_fluid) (x,y,u,v; m must equal rho0*vol) and boundary[0..n_boundary) (x,y, and u,v: the
+ * fluid-boundary viscosity term reads the wall particle's stored velocity, :357; walls themselves do not move),
  * computes psi, bins everything, evaluates rho, p and a at t = 0 under gravity (gx,gy).
  * device = HIP device ordinal. */
 int  sph_create(sph_ctx **out, const sph_params *prm,

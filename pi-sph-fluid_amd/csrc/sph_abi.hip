@@ -361,13 +361,13 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
     ALLOC(a.dirty, tiles);
-    ALLOC(a.bpos, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
+    ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 64 * 128);
     ALLOC(ctx->d_ids, n);
-    float2 *bpos_in = nullptr;
+    float2 *bpos_in = nullptr, *bvel_in = nullptr;
     uint32_t *bkey = nullptr;
-    ALLOC(bpos_in, nb); ALLOC(bkey, nb);
+    ALLOC(bpos_in, nb); ALLOC(bvel_in, nb); ALLOC(bkey, nb);
     a.send[0] = a.send[1] = a.recv[0] = a.recv[1] = nullptr;
     if (slab) {
         ctx->halo_bytes = sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * slab->halo_cap);
@@ -392,14 +392,19 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemcpyAsync(a.dn, hdn, sizeof hdn, hipMemcpyHostToDevice, st));
 
     // boundary: bin once, pseudo-mass once (:600-601)
-    std::vector<float2> hb(nb ? nb : 1);
+    std::vector<float2> hb(nb ? nb : 1), hbv(nb ? nb : 1);
     std::vector<float> hpsi(nb ? nb : 1);
-    for (size_t i = 0; i < nb; i++) { hb[i] = make_float2(boundary[i].x, boundary[i].y); hpsi[i] = boundary[i].m; }
+    for (size_t i = 0; i < nb; i++) {
+        hb[i] = make_float2(boundary[i].x, boundary[i].y);
+        hbv[i] = make_float2(boundary[i].u, boundary[i].v);      // read by the viscosity term (:357); walls do not move
+        hpsi[i] = boundary[i].m;
+    }
     HIPCHK(ctx, hipMemcpyAsync(bpos_in, hb.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(bvel_in, hbv.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
     launch_set_rebuild(st, a, true);        // the scan is a rebuild kernel
     launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.dirty, a.flags, n_boundary);
     launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild);
-    launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary);
+    launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary, bvel_in, a.bvel);
     if (psi_given) {
         // psi was computed on the full wall set (a slab sees only its part of the walls): scatter it to bin order
         float *psi_in = reinterpret_cast<float *>(bkey);      // bkey is dead after the reorder

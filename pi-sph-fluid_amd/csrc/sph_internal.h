@@ -75,6 +75,7 @@ struct Arrays {
     uint32_t *block_sums; // scan scratch
     // boundary, sorted once at init
     float2 *bpos;
+    float2 *bvel;       // the wall particles' stored u, v (the viscosity term reads them, :357; 0 in the reference's scenes)
     float *bpsi;
     uint32_t *bid;
     uint32_t *bcell_start; // n_cells + 1
@@ -167,7 +168,8 @@ void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, int
 void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in, uint32_t *key, uint32_t *slot,
                          uint32_t *count, uint32_t *dirty, uint32_t *flags, int nb);
 void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
-                             const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb);
+                             const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb, const float2 *bvel_in,
+                             float2 *bvel);
 void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb);
 void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *psi_in_original_order, int nb);
 // read-back helpers

@@ -717,7 +717,8 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
                                                       const uint32_t *__restrict__ cs, const float2 *__restrict__ bpos,
                                                       const float *__restrict__ bpsi, const uint32_t *__restrict__ bcs,
                                                       const float2 *__restrict__ grav, float2 *__restrict__ acc,
-                                                      float2 *__restrict__ velt, const uint32_t *__restrict__ dn) {
+                                                      float2 *__restrict__ velt, const uint32_t *__restrict__ dn,
+                                                      const float2 *__restrict__ bvel) {
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= (int)dn[0]) return;
     float2 pi = pos[i], vi = vel[i], rpi = rp[i];
@@ -751,7 +752,8 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
             float dx = pi.x - pj.x, dy = pi.y - pj.y;
             float d2 = fmaf(dx, dx, dy * dy);
             if (d2 < c.cut2 && d2 > 0.0f) {
-                float xv = fmaf(dx, vi.x, dy * vi.y);                              // boundary velocity = 0 :357
+                float2 vb = bvel[j];                                               // the wall particle's stored u, v :357
+                float xv = fmaf(dx, vi.x - vb.x, dy * (vi.y - vb.y));
                 float cf = bpsi[j] * pair_coef(c, d2, xv, rpi.y, rpi.x);           // :350, :362
                 bx = fmaf(cf, dx, bx);
                 by = fmaf(cf, dy, by);
@@ -792,10 +794,10 @@ void launch_force(hipStream_t st, const Consts &c, const Arrays &a, int cap, int
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
     if (mode != FORCE_EVAL)
         hipLaunchKernelGGL(k_force_direct<true>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.skey, a.cell_start, a.bpos, a.bpsi,
-                           a.bcell_start, a.grav, a.acc, a.velt, a.dn);
+                           a.bcell_start, a.grav, a.acc, a.velt, a.dn, a.bvel);
     else
         hipLaunchKernelGGL(k_force_direct<false>, g, b, 0, st, c, a.pos, a.vel, a.rp, a.skey, a.cell_start, a.bpos, a.bpsi,
-                           a.bcell_start, a.grav, a.acc, a.velt, a.dn);
+                           a.bcell_start, a.grav, a.acc, a.velt, a.dn, a.bvel);
 }
 
 // slab mode read-back: the owned particles (sorted order) as compact AoS + their global ids (+ accelerations)
@@ -850,11 +852,13 @@ __global__ __launch_bounds__(BLK) void k_boundary_reorder(const float2 *__restri
                                                           const uint32_t *__restrict__ key,
                                                           const uint32_t *__restrict__ slot,
                                                           const uint32_t *__restrict__ cell_start,
-                                                          float2 *__restrict__ bpos, uint32_t *__restrict__ bid, int nb) {
+                                                          float2 *__restrict__ bpos, uint32_t *__restrict__ bid, int nb,
+                                                          const float2 *__restrict__ bvel_in, float2 *__restrict__ bvel) {
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= nb) return;
     uint32_t dst = cell_start[key[i]] + slot[i];
     bpos[dst] = bpos_in[i];
+    bvel[dst] = bvel_in[i];
     bid[dst] = (uint32_t)i;
 }
 
@@ -900,10 +904,11 @@ void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in,
                        flags, nb);
 }
 void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
-                             const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb) {
+                             const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb, const float2 *bvel_in,
+                             float2 *bvel) {
     if (nb <= 0) return;
     hipLaunchKernelGGL(k_boundary_reorder, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, bpos_in, key, slot, cell_start,
-                       bpos, bid, nb);
+                       bpos, bid, nb, bvel_in, bvel);
 }
 void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb) {
     if (nb <= 0) return;
@@ -934,12 +939,13 @@ __global__ __launch_bounds__(BLK) void k_unsort_accel(const float2 *__restrict__
     dv[k] = a.y;
 }
 __global__ __launch_bounds__(BLK) void k_unsort_boundary(Consts c, const float2 *__restrict__ bpos,
+                                                         const float2 *__restrict__ bvel,
                                                          const float *__restrict__ bpsi, const uint32_t *__restrict__ bid,
                                                          sph_particle *__restrict__ out, int nb) {
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= nb) return;
     sph_particle q;
-    q.x = bpos[i].x; q.y = bpos[i].y; q.u = 0; q.v = 0; q.m = bpsi[i]; q.rho = c.rho0; q.p = 0;
+    q.x = bpos[i].x; q.y = bpos[i].y; q.u = bvel[i].x; q.v = bvel[i].y; q.m = bpsi[i]; q.rho = c.rho0; q.p = 0;
     out[bid[i]] = q;
 }
 __global__ __launch_bounds__(BLK) void k_upload_state(const sph_particle *__restrict__ in, float2 *__restrict__ pos,
@@ -971,7 +977,7 @@ void launch_unsort_accel(hipStream_t st, const Arrays &a, int n, float *du, floa
 }
 void launch_unsort_boundary(hipStream_t st, const Consts &c, const Arrays &a, int nb, sph_particle *out_dev) {
     if (nb <= 0) return;
-    hipLaunchKernelGGL(k_unsort_boundary, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.bpos, a.bpsi, a.bid, out_dev, nb);
+    hipLaunchKernelGGL(k_unsort_boundary, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.bpos, a.bvel, a.bpsi, a.bid, out_dev, nb);
 }
 void launch_upload_state(hipStream_t st, const Arrays &a, int n, const sph_particle *in_dev) {
     if (n <= 0) return;

@@ -407,3 +407,30 @@ def test_random_clusters_vs_oracle(sph, orc, oracle, seed):
             ctx.eval_accel(GX, GY)
             gdu, gdv = ctx.read_accel()
             assert np.max(np.hypot(gdu - du, gdv - dv) / (sa + G)) <= TOL, variant
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wall_velocity_enters_the_viscosity_term(sph, orc, oracle, variant):
+    """the reference's fluid-boundary viscosity reads the wall particle's stored u, v (pi_sph_fluid.c:357); its own
+    scenes leave them 0.  With non-zero wall velocities (a sliding floor) the staged G3 gate must still hold, and the
+    result must differ from the wall-at-rest one."""
+    g = load_golden("drop.npz")
+    box = (0.0, 4.0, 0.0, 2.0)
+    state, rho_ref, p_ref = g["state_2000"], g["rho_2000"], g["p_2000"]     # fluid resting on the floor
+    prm = sph.default_params(box)
+    b = boundary_particles(orc, g["boundary_xy"])
+    b["u"] = np.where(g["boundary_xy"][:, 1] == 0.0, 3.0, 0.0)              # the floor slides at 3 m/s
+    b["v"] = 0.25
+    fin = particles(orc, state, m_fluid(prm), rho=rho_ref, p=p_ref)
+    with sph.Context(prm, fin, b, GX, GY) as ctx:
+        ctx.set_variant(variant)
+        gb = ctx.read_boundary()
+        assert np.array_equal(gb["u"], b["u"]) and np.array_equal(gb["v"], b["v"])
+        ctx.upload_state(fin)
+        ctx.eval_accel(GX, GY)
+        du, dv = ctx.read_accel()
+    bpsi = b.copy()
+    bpsi["m"] = g["psi"]
+    odu, odv, sa = sum_abs_terms(oracle, box, fin, bpsi)
+    assert np.max(np.hypot(du - odu, dv - odv) / (sa + G)) <= TOL
+    assert np.max(np.hypot(odu - g["eval_du_2000"], odv - g["eval_dv_2000"])) > 1e-2    # the wall velocity matters
