@@ -29,6 +29,7 @@ for s in range(3):
 span = khi - klo
 print("blocks", nb, "total: mean %.0f p50 %d p90 %d p99 %d max %d ; >1152: %.1f%%  >1280: %.1f%%" % (
     tot.mean(), np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), 100 * np.mean(tot > 1152), 100 * np.mean(tot > 1280)))
+print("tiles above", {t: int((tot > t).sum()) for t in (896, 960, 1024, 1056, 1088, 1120, 1152)})
 print("span: mean %.0f p50 %d p90 %d p99 %d max %d ; >250: %.1f%%" % (span.mean(), np.percentile(span, 50), np.percentile(span, 90), np.percentile(span, 99), span.max(), 100 * np.mean(span > 250)))
 cnt = np.diff(cs); occ = cnt[cnt > 0]
 print("particles per occupied cell: mean %.2f max %d ; per 3-cell column range max %d" % (occ.mean(), occ.max(), np.convolve(cnt, np.ones(3, int), "same").max()))
