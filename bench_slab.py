@@ -34,6 +34,12 @@ class HostStagedTransport:
             self.dist.all_reduce(f, op=self.dist.ReduceOp.MAX)
             self.slab.flag_set(int(f.item()))
 
+    def exchange_start(self):
+        self.exchange()
+
+    def exchange_finish(self, handle):
+        pass
+
     def exchange(self):
         t, d, ops = self.torch, self.dist, []
         if self.rank > 0:

@@ -186,6 +186,7 @@ int  sph_set_variant(sph_ctx *ctx, int variant);
  *     -- reduce the word over all ranks --
  *     sph_slab_step_pack()    fills the send buffers (kind 0 or 1 according to the word)
  *     -- move send_right -> right neighbour's recv_left, send_left -> left neighbour's recv_right --
+ *     sph_slab_step_overlap() optional, while the buffers move: density of the tiles that stage no ghost particle
  *     sph_slab_step_end()     ingest + sort + lists (kind 0) or ghost update (kind 1), density + EOS + force + kick (:626-640) */
 typedef struct sph_slab_desc {
     int col_begin, col_end;      /* owned global cell columns [begin, end), at least 4 */
@@ -201,6 +202,7 @@ int  sph_create_slab(sph_ctx **out, const sph_params *prm, const sph_slab_desc *
                      const sph_particle *boundary_all, int n_boundary_all, float gx, float gy, int device);
 int  sph_slab_step_begin(sph_ctx *ctx, float gx, float gy);
 int  sph_slab_step_pack(sph_ctx *ctx);
+int  sph_slab_step_overlap(sph_ctx *ctx);
 int  sph_slab_step_end(sph_ctx *ctx);
 /* the rebuild word: its device address (library-owned unless replaced), adopting a word of the host framework
  * (e.g. a 1-element int32 torch tensor handed to RCCL; NULL = back to the library's own), host-staged access */

@@ -28,6 +28,7 @@ struct sph_ctx {
     int cap = 0;                // capacity of the particle arrays (== n in single mode)
     bool slab = false;
     int slab_phase = 0;         // 0 idle, 1 after sph_slab_step_begin, 2 after sph_slab_step_pack
+    bool slab_overlapped = false; // sph_slab_step_overlap ran in this step: step_end's density does the rest only
     bool own_halo = false;      // halo buffers allocated by the library (else adopted from the host framework)
     size_t halo_bytes = 0;
     uint32_t *d_ids = nullptr;  // slab read-back staging
@@ -381,6 +382,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
     a.rebuild = a.flags + FLAG_REBUILD;
     a.check = a.flags + FLAG_CHECK;
+    a.latch = a.flags + FLAG_LATCH;
     ctx->pos_a = a.pos;
     HIPCHK(ctx, hipMemsetAsync(a.acc, 0, (n ? n : 1) * sizeof(float2), st));
     if (slab)
@@ -762,6 +764,17 @@ int sph_slab_step_pack(sph_ctx *ctx) {
     return SPH_OK;
 }
 
+int sph_slab_step_overlap(sph_ctx *ctx) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (!ctx->slab || ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_step_overlap without sph_slab_step_pack");
+    (void)hipSetDevice(ctx->device);
+    // density of the tiles that stage no ghost particle (nothing on a rebuild step): independent of the incoming halo
+    launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_INTERIOR);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->slab_overlapped = true;
+    return SPH_OK;
+}
+
 int sph_slab_step_end(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     if (!ctx->slab || ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_pack");
@@ -772,9 +785,10 @@ int sph_slab_step_end(sph_ctx *ctx) {
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     launch_canon(st, ctx->c, ctx->a);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
-    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true);
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, ctx->slab_overlapped ? DENS_REST : DENS_ALL);
     launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
+    ctx->slab_overlapped = false;
     ctx->slab_phase = 0;
     return SPH_OK;
 }

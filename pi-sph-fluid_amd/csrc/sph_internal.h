@@ -84,6 +84,7 @@ struct Arrays {
     uint32_t *flags;    // see FLAG_*
     float4 *wbox;       // per group of BOXG consecutive sorted particles: bounding box of displacement since the last rebuild
     uint32_t *wnbr;     // per group: WNBR_WORDS words = 5 x {first, last} group whose particles may come near this group's
+    uint32_t *latch;    // slab mode: copy of the reduced rebuild word of the current step (flags + FLAG_LATCH)
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
@@ -104,6 +105,7 @@ enum {
     FLAG_MISMATCH = 8,      // slab mode: a halo message did not match the step (kind or length): ranks out of step
     FLAG_CHECK = 9,         // set by the drifting kernel: a particle is beyond skin/2, the wave boxes need comparing
     FLAG_NCHECK = 10,       // steps in which k_check ran
+    FLAG_LATCH = 11,        // slab mode: the reduced rebuild word of this step, latched by k_halo_in for the final density pass
     FLAG_COUNT = 12
 };
 constexpr int TILE_WORDS = 16;           // 32-bit words per tile record
@@ -156,9 +158,12 @@ void launch_build_list(hipStream_t st, const Consts &c, const Arrays &a, int cap
 // variant: 0 = LDS-tiled neighbour lists (default), 1 = direct global loads over the cell ranges (A/B measurements)
 // mode: what the density pass writes
 enum { DENS_RHO = 0, DENS_RHO_EOS = 1 };
-// consume_rebuild: this is the density pass of a step, it clears the rebuild word (the rebuild kernels in front of it
-// have served the request)
-void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild);
+// consume_rebuild: this is the (final) density pass of a step, it clears the rebuild word (the rebuild kernels in front
+// of it have served the request).  pass (slab mode: overlap with the halo exchange): DENS_ALL; DENS_INTERIOR = only the
+// tiles that stage no ghost, and nothing at all on a rebuild step; DENS_REST = what DENS_INTERIOR left out.
+enum { DENS_ALL = 0, DENS_INTERIOR = 1, DENS_REST = 2 };
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild,
+                    int pass = DENS_ALL);
 // what the force pass writes besides a: nothing / velt (second half kick) / velt + the next step's kick 1/2 + drift
 // into pos2, vel2 + the next step's rebuild request
 enum { FORCE_EVAL = 0, FORCE_KICK = 1, FORCE_KICK_DRIFT = 2 };

@@ -451,6 +451,7 @@ __global__ __launch_bounds__(BLK) void k_halo_in(Consts c, const uint32_t *__res
                                                  uint32_t *__restrict__ flags, const uint32_t *__restrict__ rebuild,
                                                  uint32_t *__restrict__ dn, int stage_cap, float2 *__restrict__ pos,
                                                  float2 *__restrict__ vel, const uint32_t *__restrict__ cs, int halo_blocks) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[FLAG_LATCH] = *rebuild;      // for the final density pass (DENS_REST)
     if (*rebuild != 0u) {
         ingest_body(c, recv_l, recv_r, velk, pk, slot, count, dirty, flags, dn, stage_cap);
     } else {
@@ -773,9 +774,11 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
 
 namespace sph {
 
-void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild) {
+void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild,
+                    int pass) {
     if (cap <= 0) return;
-    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild); return; }
+    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild, pass); return; }
+    if (pass == DENS_INTERIOR) return;      // the direct variant is not split: everything in the final pass
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
     uint32_t *rb = consume_rebuild ? a.rebuild : nullptr;
     if (mode == DENS_RHO_EOS)

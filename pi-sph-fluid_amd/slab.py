@@ -142,6 +142,9 @@ class GpuSlab:
     def step_pack(self):
         self._chk(self.L.sph_slab_step_pack(self.h))
 
+    def step_overlap(self):
+        self._chk(self.L.sph_slab_step_overlap(self.h))
+
     def step_end(self):
         self._chk(self.L.sph_slab_step_end(self.h))
 
@@ -218,6 +221,12 @@ class LocalTransport:
             for x in s:
                 x.flag_set(any_set)
 
+    def exchange_start(self):
+        self.exchange()
+
+    def exchange_finish(self, handle):
+        pass
+
     def exchange(self):
         s = self.slabs
         for r in range(len(s) - 1):
@@ -242,7 +251,8 @@ class TorchTransport:
         if self.world > 1:
             self.dist.all_reduce(self.flag, op=self.dist.ReduceOp.MAX)
 
-    def exchange(self):
+    def exchange_start(self):
+        """post the sends / receives; they run beside whatever is enqueued next (the interior density pass)."""
         d, ops = self.dist, []
         if self.rank > 0:
             ops.append(d.P2POp(d.isend, self.send_l, self.rank - 1))
@@ -250,18 +260,25 @@ class TorchTransport:
         if self.rank < self.world - 1:
             ops.append(d.P2POp(d.isend, self.send_r, self.rank + 1))
             ops.append(d.P2POp(d.irecv, self.recv_r, self.rank + 1))
-        if ops:
-            for w in d.batch_isend_irecv(ops):
-                w.wait()
+        return d.batch_isend_irecv(ops) if ops else []
+
+    def exchange_finish(self, handle):
+        for w in handle:
+            w.wait()
+
+    def exchange(self):
+        self.exchange_finish(self.exchange_start())
 
 
 class SlabRunner:
-    """nsteps of: kick/drift -> reduce the rebuild word -> halo pack -> exchange -> (ingest + sort + lists | ghost
-    update) + density + force (pi_sph_fluid.c:612-641)."""
+    """nsteps of: kick/drift -> reduce the rebuild word -> halo pack -> exchange (beside it: density of the interior
+    tiles) -> (ingest + sort + lists | ghost update) + density of the rest + force (pi_sph_fluid.c:612-641)."""
 
-    def __init__(self, slabs, transport):
+    def __init__(self, slabs, transport, overlap=None):
         self.slabs = slabs if isinstance(slabs, (list, tuple)) else [slabs]
         self.transport = transport
+        # splitting the density pass costs one more launch: worth it only when there is an exchange to hide
+        self.overlap = (len(self.slabs) > 1 or getattr(transport, "world", 1) > 1) if overlap is None else overlap
 
     def step(self, nsteps=1, gx=0.0, gy=-9.81):
         for _ in range(nsteps):
@@ -270,7 +287,11 @@ class SlabRunner:
             self.transport.reduce_flag()
             for s in self.slabs:
                 s.step_pack()
-            self.transport.exchange()
+            handle = self.transport.exchange_start()
+            if self.overlap:
+                for s in self.slabs:
+                    s.step_overlap()         # density of the tiles that stage no ghost, beside the halo exchange
+            self.transport.exchange_finish(handle)
             for s in self.slabs:
                 s.step_end()
 

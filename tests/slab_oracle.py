@@ -70,6 +70,9 @@ class OracleSlab:
         o["x"] = o["x"] + self.dt * o["u"]                                                                     # :622
         o["y"] = o["y"] + self.dt * o["v"]
 
+    def step_overlap(self):
+        pass
+
     def step_pack(self):
         if getattr(self, "_flag", None) is not None:
             assert int(self._flag[0]) == 1            # MAX over ranks of words that are all 1

@@ -144,3 +144,37 @@ def test_slab_reuses_lists_between_rebuilds(sph, orc):
                 s.close()
     finally:
         sph.set_default_skin(old)
+
+
+def test_step_overlap_is_optional(sph, orc):
+    """sph_slab_step_overlap (density of the interior tiles beside the exchange) is an optimisation: a host that never
+    calls it, or calls it in some steps only, gets the same result."""
+    g = load_golden("block.npz")
+    prm = sph.default_params(tuple(g["box"]))
+    f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))
+    b = boundary_particles(orc, g["boundary_xy"])
+    res = []
+    for mode in ("always", "never", "alternate"):
+        slabs, runner = build(sph, prm, f, b, 3)
+        for k in range(30):
+            for s in slabs:
+                s.step_begin(GX, GY)
+            runner.transport.reduce_flag()
+            for s in slabs:
+                s.step_pack()
+            runner.transport.exchange()
+            if mode == "always" or (mode == "alternate" and k % 2 == 0):
+                for s in slabs:
+                    s.step_overlap()
+            for s in slabs:
+                s.step_end()
+        for s in slabs:
+            s.sync()
+        out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+        assert np.all(seen == 1)
+        res.append(out)
+        for s in slabs:
+            s.close()
+    for other in res[1:]:
+        assert np.max(np.abs(other["x"] - res[0]["x"])) <= 2e-5 and np.max(np.abs(other["y"] - res[0]["y"])) <= 2e-5
+        assert np.max(np.abs(other["rho"] - res[0]["rho"]) / res[0]["rho"]) <= 2e-4
