@@ -85,7 +85,7 @@ def run_single(sph, name, steps, warmup, profile_steps=20):
     res = {"workload": name, "n_fluid": n, "n_boundary": len(b), "grid_cells": rows * cols,
            "steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
            "mparticle_steps_per_s": steps / dt * n / 1e6, "kernel_ms": kt,
-           "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s, "skin_frac": sph.default_skin(),
+           "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s, "skin_frac": float(prm.skin),
            "rebuilds": rebuilds, "direct_tiles": direct_tiles, "timed_rebuilds_per_step": (r1 - r0) / max(steps, 1),
            "device_mb": ctx.device_bytes() / 1e6}
     ctx.close()

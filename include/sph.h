@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 2
+#define SPH_ABI_VERSION 3
 
 typedef enum sph_error {
     SPH_OK = 0,
@@ -60,6 +60,8 @@ typedef struct sph_params {
     float eps;    /* 0.01   viscosity singularity guard        :332 */
     float k1;     /* 0.1    artificial pressure strength       :325 */
     float k2;     /* 0.2    artificial pressure reference q    :325 */
+    float skin;   /* 0.15   Verlet skin of the neighbour structure as a fraction of 2H (no reference counterpart: the
+                            reference rebuilds every step, :626 = skin 0).  Per context; see "neighbour-structure reuse" */
 } sph_params;
 
 typedef struct sph_ctx sph_ctx;
@@ -138,10 +140,8 @@ int  sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell);
  * so a jet moving as a whole keeps its lists) and nobody has moved more than H + skin.  Until then no unlisted pair
  * can be inside the support 2H, and listed pairs beyond 2H contribute exactly 0.  Results do not depend on the skin
  * (beyond summation order).  skin = 0: a rebuild whenever neighbouring particles moved relative to each other at all.
- * The skin is a fraction of 2H, process-wide, read by sph_create / sph_create_slab (default: $SPH_SKIN or 0.15). */
-int   sph_set_default_skin(float fraction_of_2h);
-float sph_default_skin(void);
-/* cell length of the device grid for these parameters and the current default skin (what slab hosts must bin with) */
+ * The skin is sph_params.skin (a fraction of 2H, 0 <= skin <= 1), fixed per context at creation. */
+/* cell length of the device grid for these parameters: 2H (1 + skin) — what slab hosts must bin with */
 float sph_device_cell(const sph_params *prm);
 /* rebuilds since creation, and tiles that list builds have put on the direct (no list) path */
 int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
@@ -151,8 +151,13 @@ int   sph_check_stats(sph_ctx *ctx, long long *checks);
 long long sph_out_of_domain_count(sph_ctx *ctx);
 
 /* ---- stage entry points: the individual calculate_* calls, for staged parity gates ---- */
-/* overwrite x,y,u,v AND rho,p of every fluid particle (original order) and re-bin (:604) */
+/* overwrite x,y,u,v AND rho,p of every fluid particle (original order) and re-bin (:604).  The stored accelerations
+ * stay aligned with their particles (reference: du_dt[] is indexed like fluid[], :616), so
+ * sph_upload_state(sph_read_particles()) followed by sph_step() continues the run it was read from. */
 int  sph_upload_state(sph_ctx *ctx, const sph_particle *fluid);
+/* overwrite du_dt[], dv_dt[] (original order): with sph_upload_state this restores a checkpoint taken with
+ * sph_read_particles + sph_read_accel */
+int  sph_upload_accel(sph_ctx *ctx, const float *du_dt, const float *dv_dt);
 int  sph_eval_density(sph_ctx *ctx);                       /* calculate_density :263-289, rho only */
 int  sph_eval_pressure(sph_ctx *ctx);                      /* calculate_particle_pressure :294-301, from the stored rho */
 int  sph_eval_accel(sph_ctx *ctx, float gx, float gy);     /* calculate_accelerations :303-373, from the stored x,y,u,v,rho,p */
@@ -162,7 +167,9 @@ int  sph_eval_accel(sph_ctx *ctx, float gx, float gy);     /* calculate_accelera
 int  sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_times *out);
 /* mean device time [ms] of `reps` back-to-back launches of ONE per-step kernel on the live state, between two HIP
  * events on the context's stream.  Only the idempotent kernels (SPH_K_DENSITY_EOS, SPH_K_FORCE_KICK: same
- * inputs -> same outputs, nothing they read is overwritten) can be timed this way; others give SPH_E_ARG. */
+ * inputs -> same outputs, nothing they read is overwritten) can be timed this way; others give SPH_E_ARG.
+ * SPH_K_FORCE_KICK re-does the kick of the last step: valid only after at least one sph_step since creation / upload /
+ * sph_eval_accel (SPH_E_STATE otherwise: the velocities would be kicked a second time). */
 int  sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms);
 /* adopt an existing hipStream_t (e.g. the host framework's current stream); NULL = own stream */
 int  sph_set_stream(sph_ctx *ctx, void *hip_stream);

@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_HIP = os.environ.get("SPH_LIB_HIP") or os.path.join(HERE, "csrc", "libsph_hip.so")   # override: A/B builds only
+LIB_HIP = os.path.join(HERE, "csrc", "libsph_hip.so")      # (measurement scripts may point this at an A/B build before first use)
 LIB_HOST = os.path.join(HERE, "host", "libsph_host.so")
 
 # byte-compatible with the reference's `struct particle` (pi_sph_fluid.c:26-31)
@@ -38,8 +38,8 @@ ABI_SYMBOLS = [
     "sph_create", "sph_destroy", "sph_last_error", "sph_step", "sph_sync",
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
-    "sph_set_default_skin", "sph_default_skin", "sph_device_cell", "sph_rebuild_stats", "sph_check_stats",
-    "sph_upload_state", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
+    "sph_device_cell", "sph_rebuild_stats", "sph_check_stats",
+    "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
     "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
     "sph_render_metaballs",
     "sph_create_slab", "sph_slab_step_begin", "sph_slab_step_pack", "sph_slab_step_overlap", "sph_slab_step_end",
@@ -57,7 +57,8 @@ class Params(C.Structure):
     _fields_ = [("r", C.c_float), ("h", C.c_float), ("rho0", C.c_float), ("c", C.c_float),
                 ("g", C.c_float), ("dt", C.c_float), ("vol", C.c_float),
                 ("x_min", C.c_float), ("x_max", C.c_float), ("y_min", C.c_float), ("y_max", C.c_float),
-                ("alpha", C.c_float), ("eps", C.c_float), ("k1", C.c_float), ("k2", C.c_float)]
+                ("alpha", C.c_float), ("eps", C.c_float), ("k1", C.c_float), ("k2", C.c_float),
+                ("skin", C.c_float)]
 
 
 class KernelTimes(C.Structure):
@@ -125,13 +126,12 @@ def hip_lib():
         L.sph_out_of_domain_count.argtypes = [vp]
         L.sph_out_of_domain_count.restype = C.c_longlong
         L.sph_device_grid.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(cf)]
-        L.sph_set_default_skin.argtypes = [cf]
-        L.sph_default_skin.restype = cf
         L.sph_device_cell.argtypes = [C.POINTER(Params)]
         L.sph_device_cell.restype = cf
         L.sph_rebuild_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.sph_check_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.sph_upload_state.argtypes = [vp, vp]
+        L.sph_upload_accel.argtypes = [vp, vp, vp]
         L.sph_eval_density.argtypes = [vp]
         L.sph_eval_pressure.argtypes = [vp]
         L.sph_eval_accel.argtypes = [vp, cf, cf]
@@ -184,11 +184,15 @@ def host_lib():
     return _host
 
 
-def default_params(box=None):
+def default_params(box=None, skin=None):
+    """reference defaults (:11-20); box = (x_min, x_max, y_min, y_max); skin = Verlet skin as a fraction of 2H
+    (None: the library default; 0: rebuild the neighbour structure every step like the reference, :626)."""
     p = Params()
     host_lib().sph_params_default(C.byref(p))
     if box is not None:
         p.x_min, p.x_max, p.y_min, p.y_max = [float(v) for v in box]
+    if skin is not None:
+        p.skin = float(skin)
     return p
 
 
@@ -241,17 +245,6 @@ def scene(name):
 def dam_break(n_slabs):
     """The cfg2 -> cfg3 family: one 4000 x 500 block (2M particles, 1200 m of box) per slab."""
     return scene_block((0.0, 1200.0 * n_slabs, 0.0, 60.0), 0.3, 0.3, 4000 * n_slabs, 500)
-
-
-def set_default_skin(fraction_of_2h):
-    """Verlet skin of contexts created from now on, as a fraction of 2H (0 = rebuild the neighbour structure every step)."""
-    rc = hip_lib().sph_set_default_skin(float(fraction_of_2h))
-    if rc:
-        raise SphError(rc, "skin must be within [0, 1]")
-
-
-def default_skin():
-    return float(hip_lib().sph_default_skin())
 
 
 class GravitySource:
@@ -364,6 +357,11 @@ class Context:
         fluid = np.ascontiguousarray(fluid, PARTICLE)
         assert len(fluid) == self.n
         self._chk(self.L.sph_upload_state(self.h, fluid.ctypes.data_as(C.c_void_p)))
+
+    def upload_accel(self, du, dv):
+        du, dv = np.ascontiguousarray(du, np.float32), np.ascontiguousarray(dv, np.float32)
+        assert len(du) == self.n and len(dv) == self.n
+        self._chk(self.L.sph_upload_accel(self.h, du.ctypes.data_as(C.c_void_p), dv.ctypes.data_as(C.c_void_p)))
 
     def eval_density(self):
         self._chk(self.L.sph_eval_density(self.h))

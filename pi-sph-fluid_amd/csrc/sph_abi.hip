@@ -37,7 +37,7 @@ struct sph_ctx {
     sph_particle *d_aos = nullptr;    // n  : read-back / upload staging, original order
     sph_particle *d_baos = nullptr;   // nb
     float *d_du = nullptr, *d_dv = nullptr;
-    unsigned char *d_bits = nullptr;  // 8192 metaball pixels
+    unsigned char *d_bits = nullptr;  // metaball frame, 1024 bytes of SSD1306 page format
     std::vector<void *> allocs;
     size_t bytes = 0;
     // Single-GPU step with the list kernels: the force pass of step s also does step s+1's kick 1/2 + drift into the
@@ -45,6 +45,7 @@ struct sph_ctx {
     // that look-ahead (false after creation / upload / eval_accel / variant change: the next step then starts with
     // the stand-alone kick/drift kernel instead).  One captured graph per orientation of the two sets.
     bool primed = false;
+    bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
     hipGraph_t graph[2] = {nullptr, nullptr};
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
@@ -55,19 +56,6 @@ struct sph_ctx {
 };
 
 namespace {
-
-// process-wide default skin as a fraction of 2H (sph_set_default_skin / $SPH_SKIN); < 0 = not set yet.
-// 0.15 measured best on the 2M-particle dam break (0.03 ... 0.3 are within 15 % of it).
-constexpr float SKIN_FRAC_DEFAULT = 0.15f;
-float g_skin_frac = -1.0f;
-float default_skin_frac() {
-    if (g_skin_frac < 0.0f) {
-        const char *e = getenv("SPH_SKIN");
-        const float v = e ? (float)atof(e) : SKIN_FRAC_DEFAULT;
-        g_skin_frac = (v >= 0.0f && v <= 1.0f) ? v : SKIN_FRAC_DEFAULT;
-    }
-    return g_skin_frac;
-}
 
 int fail(sph_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
     if (ctx) {
@@ -98,7 +86,9 @@ int dalloc(sph_ctx *ctx, T **p, size_t count) {
 }
 
 // derived constants, evaluated like the reference's macros (double where its expression is double)
-int make_consts(const sph_params &p, float skin_frac, Consts &c) {
+int make_consts(const sph_params &p, Consts &c) {
+    const float skin_frac = p.skin;      // per context (sph_params.skin), a fraction of 2H
+    if (!(skin_frac >= 0.0f && skin_frac <= 1.0f)) return SPH_E_ARG;
     if (!(p.h > 0) || !(p.r > 0) || !(p.rho0 > 0) || !(p.c > 0) || !(p.dt > 0) || !(p.vol > 0)) return SPH_E_ARG;
     if (!(p.x_max > p.x_min) || !(p.y_max > p.y_min)) return SPH_E_ARG;
     const double H = p.h;
@@ -216,6 +206,7 @@ int run_step(sph_ctx *ctx, hipEvent_t *ev) {
         launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, false);
     }
     ctx->primed = fused(ctx);
+    ctx->stepped = true;
     hipGraphExec_t g = ev ? nullptr : step_graph(ctx);
     if (g) HIPCHK(ctx, hipGraphLaunch(g, st));
     else enqueue_step_body(ctx, ev);
@@ -315,7 +306,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
                  const sph_particle *boundary, int n_boundary, bool psi_given, float gx, float gy, int device,
                  const SlabSpec *slab) {
     ctx->prm = *prm;
-    if (make_consts(*prm, default_skin_frac(), ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "invalid parameters or grid too large");
+    if (make_consts(*prm, ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "invalid parameters (skin must be within [0, 1]) or grid too large");
     ctx->skin = ctx->c.cell - 2 * prm->h;
     if (slab) {
         Consts &c = ctx->c;
@@ -342,8 +333,6 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ctx->nb = n_boundary;
     ctx->cap = slab ? slab->particle_cap : n_fluid;
     if (ctx->cap < n_fluid) return fail(ctx, SPH_E_ARG, "particle capacity smaller than the initial particle count");
-    if (const char *e = getenv("SPH_NO_GRAPH")) ctx->use_graph = !(e[0] == '1');
-    if (const char *e = getenv("SPH_VARIANT")) ctx->variant = atoi(e);
 
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
@@ -364,7 +353,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
-    ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 64 * 128);
+    ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 1024);
     ALLOC(ctx->d_ids, n);
     float2 *bpos_in = nullptr, *bvel_in = nullptr;
     uint32_t *bkey = nullptr;
@@ -469,7 +458,7 @@ int sph_create_slab(sph_ctx **out, const sph_params *prm, const sph_slab_desc *d
         sph_destroy(tmp);
     }
     Consts cg;
-    if (make_consts(*prm, default_skin_frac(), cg) != SPH_OK) return fail(ctx, SPH_E_ARG, "sph_create_slab: invalid parameters");
+    if (make_consts(*prm, cg) != SPH_OK) return fail(ctx, SPH_E_ARG, "sph_create_slab: invalid parameters");
     const int lo = desc->col_begin - 2, hi = desc->col_end + 2;   // local columns [lo, hi)
     std::vector<sph_particle> bloc;
     for (int i = 0; i < n_boundary_all; i++) {
@@ -570,16 +559,10 @@ int sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell) {
     if (cell) *cell = ctx->c.cell;
     return SPH_OK;
 }
-int sph_set_default_skin(float fraction_of_2h) {
-    if (!(fraction_of_2h >= 0.0f && fraction_of_2h <= 1.0f)) return SPH_E_ARG;
-    g_skin_frac = fraction_of_2h;
-    return SPH_OK;
-}
-float sph_default_skin(void) { return default_skin_frac(); }
 float sph_device_cell(const sph_params *prm) {
-    if (!prm) return 0.0f;
+    if (!prm || !(prm->skin >= 0.0f && prm->skin <= 1.0f)) return 0.0f;
     const float two_h = 2 * prm->h;
-    return two_h + default_skin_frac() * two_h;
+    return two_h + prm->skin * two_h;      // the arithmetic of make_consts
 }
 int sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
@@ -640,14 +623,34 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "stage entry points are single-GPU only");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
+    // du_dt, dv_dt stay with their particles (reference: index-aligned arrays, :616): out to original order before
+    // the arrays are rewritten, back in through the new sort order afterwards
+    launch_unsort_accel(st, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyHostToDevice, st));
     launch_upload_state(st, ctx->a, ctx->n, ctx->d_aos);
     ctx->primed = false;
+    ctx->stepped = false;
     int rc = resort_state(ctx);
     if (rc) return rc;
     launch_gather_rho_p(st, ctx->c, ctx->a, ctx->n, ctx->d_aos);
+    launch_gather_accel(st, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
     HIPCHK(ctx, hipGetLastError());
     return check_flags(ctx);
+}
+
+int sph_upload_accel(sph_ctx *ctx, const float *du_dt, const float *dv_dt) {
+    if (!ctx || !ctx->stream || ((!du_dt || !dv_dt) && ctx->n)) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "stage entry points are single-GPU only");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_du, du_dt, (size_t)ctx->n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_dv, dv_dt, (size_t)ctx->n * sizeof(float), hipMemcpyHostToDevice, st));
+    launch_gather_accel(st, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
+    ctx->primed = false;         // a look-ahead kick/drift made with the old du_dt is dropped
+    ctx->stepped = false;
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));      // the caller's buffers are free again
+    return SPH_OK;
 }
 
 int sph_eval_density(sph_ctx *ctx) {
@@ -673,6 +676,7 @@ int sph_eval_accel(sph_ctx *ctx, float gx, float gy) {
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, FORCE_EVAL, ctx->variant);
     ctx->primed = false;         // the next step kicks with THIS du_dt (:616), not with a look-ahead made before it
+    ctx->stepped = false;
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
@@ -714,6 +718,10 @@ int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_t
 int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     if (!ctx || !ctx->stream || !ms || reps <= 0) return SPH_E_ARG;
     if (kernel != SPH_K_DENSITY_EOS && kernel != SPH_K_FORCE_KICK) return fail(ctx, SPH_E_ARG, "sph_time_kernel: kernel is not idempotent");
+    // the force pass of the step writes velt = vel + dt/2 a: a repeat of the last step's kick only once a step has
+    // kicked vel; before that vel == velt and the launch would kick the velocities a second time
+    if (kernel == SPH_K_FORCE_KICK && !ctx->stepped)
+        return fail(ctx, SPH_E_STATE, "sph_time_kernel(SPH_K_FORCE_KICK) needs at least one sph_step since creation / upload");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int r = 0; r < reps; r++) {
@@ -911,16 +919,11 @@ int sph_render_metaballs(sph_ctx *ctx, unsigned char *draw_buffer) {
     if (!ctx || !ctx->stream || !draw_buffer) return SPH_E_ARG;
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_render_metaballs is single-GPU only");
     (void)hipSetDevice(ctx->device);
-    unsigned char bits[64 * 128];
+    // the kernel emits the SSD1306 page format itself (:407-408): 1 KB crosses PCIe, straight into the caller's buffer
     launch_metaballs(ctx->stream, ctx->c, ctx->a, ctx->prm.x_max - ctx->prm.x_min, ctx->prm.y_max - ctx->prm.y_min,
                      ctx->d_bits);
-    HIPCHK(ctx, hipMemcpyAsync(bits, ctx->d_bits, sizeof bits, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(draw_buffer, ctx->d_bits, 1024, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 64; i++)          // SSD1306 page format :407-408
-        for (int j = 0; j < 128; j++) {
-            if (bits[i * 128 + j]) draw_buffer[i / 8 * 128 + j] |= (unsigned char)(1 << (i % 8));
-            else draw_buffer[i / 8 * 128 + j] &= (unsigned char)~(1 << (i % 8));
-        }
     return SPH_OK;
 }
 

@@ -180,11 +180,12 @@ void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *ps
 // read-back helpers
 void launch_unsort_particles(hipStream_t st, const Consts &c, const Arrays &a, int n, sph_particle *out_dev);
 void launch_unsort_accel(hipStream_t st, const Arrays &a, int n, float *du, float *dv);
+void launch_gather_accel(hipStream_t st, const Arrays &a, int n, const float *du, const float *dv);
 void launch_unsort_boundary(hipStream_t st, const Consts &c, const Arrays &a, int nb, sph_particle *out_dev);
 void launch_upload_state(hipStream_t st, const Arrays &a, int n, const sph_particle *in_dev);
 void launch_gather_rho_p(hipStream_t st, const Consts &c, const Arrays &a, int n, const sph_particle *in_dev);
 void launch_stats(hipStream_t st, const Arrays &a, int n);
 void launch_metaballs(hipStream_t st, const Consts &c, const Arrays &a, float width, float height,
-                      unsigned char *bits_dev /* 8192 bytes, one per pixel */);
+                      unsigned char *page_bytes_dev /* 1024 bytes, SSD1306 page format */);
 
 }  // namespace sph

@@ -978,6 +978,18 @@ void launch_unsort_accel(hipStream_t st, const Arrays &a, int n, float *du, floa
     if (n <= 0) return;
     hipLaunchKernelGGL(k_unsort_accel, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, a.acc, a.id, du, dv, n);
 }
+// du_dt, dv_dt given in original order -> the sorted acc array (inverse of k_unsort_accel)
+__global__ __launch_bounds__(BLK) void k_gather_accel(const float *__restrict__ du, const float *__restrict__ dv,
+                                                      const uint32_t *__restrict__ id, float2 *__restrict__ acc, int n) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = id[i];
+    acc[i] = make_float2(du[k], dv[k]);
+}
+void launch_gather_accel(hipStream_t st, const Arrays &a, int n, const float *du, const float *dv) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_accel, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, du, dv, a.id, a.acc, n);
+}
 void launch_unsort_boundary(hipStream_t st, const Consts &c, const Arrays &a, int nb, sph_particle *out_dev) {
     if (nb <= 0) return;
     hipLaunchKernelGGL(k_unsort_boundary, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.bpos, a.bvel, a.bpsi, a.bid, out_dev, nb);
@@ -1019,13 +1031,15 @@ void launch_stats(hipStream_t st, const Arrays &a, int n) {
 }
 
 // ------------------------------------------------------------------------------------------
-// metaballs (:380-411): one thread per pixel of the 128x64 panel, pixel centres as :573
+// metaballs (:380-411): one thread per pixel of the 128x64 panel, pixel centres as :573.  The eight pixels of one
+// output byte (SSD1306 page format: bit i%8 of byte (i/8)*128 + j, :407-408) sit in eight consecutive lanes, so a wave
+// ballot holds eight finished bytes.
 __global__ __launch_bounds__(BLK) void k_metaballs(Consts c, const float2 *__restrict__ pos,
                                                    const uint32_t *__restrict__ cs, float width, float height,
-                                                   float inv_w_half_px, unsigned char *__restrict__ bits) {
-    int ij = blockIdx.x * BLK + threadIdx.x;
-    if (ij >= 64 * 128) return;
-    int i = ij / 128, j = ij % 128;
+                                                   float inv_w_half_px, unsigned char *__restrict__ page_bytes) {
+    const int t = blockIdx.x * BLK + threadIdx.x;      // grid covers exactly 64 * 128 pixels
+    const int byte = t >> 3, bit = t & 7;
+    const int i = (byte >> 7) * 8 + bit, j = byte & 127;
     float px = c.x_min + (float)((j + 0.5) * (double)width / 128.0);
     float py = c.y_min + (float)((64 - (i + 0.5)) * (double)height / 64.0);
     int row, col;
@@ -1044,16 +1058,17 @@ __global__ __launch_bounds__(BLK) void k_metaballs(Consts c, const float2 *__res
             if (d2 < c.cut2) s += w_shape(c, d2);
         }
     }
-    bits[ij] = (s * c.nf * inv_w_half_px >= 1.0f) ? 1 : 0;     // sum W / W(px/2) >= 1   :401-407
+    const unsigned long long lit = __ballot(s * c.nf * inv_w_half_px >= 1.0f);     // sum W / W(px/2) >= 1   :401-407
+    if (bit == 0) page_bytes[byte] = (unsigned char)((lit >> (threadIdx.x & 63)) & 0xffull);
 }
-void launch_metaballs(hipStream_t st, const Consts &c, const Arrays &a, float width, float height, unsigned char *bits_dev) {
+void launch_metaballs(hipStream_t st, const Consts &c, const Arrays &a, float width, float height, unsigned char *page_bytes_dev) {
     // W(px_width/2) with px_width = WIDTH/128 (:399-401), evaluated like the device W
     float half_px = width / 128.0f / 2.0f;
     float q = half_px / c.h;
     float t = 1.0f - 0.5f * q;
     float w = c.nf * (t * t) * (t * t) * (1.0f + 2.0f * q);
     hipLaunchKernelGGL(k_metaballs, dim3(64 * 128 / BLK), dim3(BLK), 0, st, c, a.pos, a.cell_start, width, height, 1.0f / w,
-                       bits_dev);
+                       page_bytes_dev);
 }
 
 }  // namespace sph

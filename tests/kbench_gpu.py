@@ -1,6 +1,7 @@
 """Manual kernel timing (not collected by pytest): cfg2 after warm-up, back-to-back launches of the two heavy
 kernels, then the force-kernel ablation builds (SPH_ABLATE bits: 1 = gathers read one address, 2 = no pair
-arithmetic, 4 = no staging).  Usage: [SPH_SKIN=f] [SPH_LIB_HIP=path] python tests/kbench_gpu.py [warmup_steps]"""
+arithmetic, 4 = no staging) when the measurement library exists (`make -C pi-sph-fluid_amd ablate`: the only build that
+reads $SPH_ABLATE).  Usage: python tests/kbench_gpu.py [warmup_steps] [skin]"""
 import importlib
 import os
 import sys
@@ -9,14 +10,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sph = importlib.import_module("pi-sph-fluid_amd")
 warm = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+ablate_lib = os.path.join(ROOT, "pi-sph-fluid_amd", "csrc", "libsph_hip_ablate.so")
+if os.path.exists(ablate_lib):
+    sph.LIB_HIP = ablate_lib
 prm, f, b = sph.dam_break(1)
+if len(sys.argv) > 2:
+    prm.skin = float(sys.argv[2])
 os.environ.pop("SPH_ABLATE", None)
 ctx = sph.Context(prm, f, b)
 ctx.step(warm)
 ctx.sync()
-print("lib %s skin %.3f rebuilds/direct tiles %s" % (os.path.basename(sph.LIB_HIP), sph.default_skin(), ctx.rebuild_stats()))
+print("lib %s skin %.3f rebuilds/direct tiles %s" % (os.path.basename(sph.LIB_HIP), prm.skin, ctx.rebuild_stats()))
 print("density %.2f us" % (ctx.time_kernel("density_eos", 50) * 1e3))
-for abl in ("0", "1", "2", "3", "4", "6", "7", "0"):
+for abl in (("0", "1", "2", "3", "4", "6", "7", "0") if sph.LIB_HIP == ablate_lib else ("0",)):
     os.environ["SPH_ABLATE"] = abl
     print("force SPH_ABLATE=%s : %.2f us" % (abl, ctx.time_kernel("force_kick", 50) * 1e3))
 os.environ.pop("SPH_ABLATE", None)

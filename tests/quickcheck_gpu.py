@@ -25,8 +25,9 @@ def compare(tag, prm, fluid, boundary, variant, steps=0):
     of, ob = fluid.copy(), boundary.copy()
     O.psi(op, ob)
     du, dv, sa = O.eval(op, of, ob, 0.0, -9.81, want_sum_abs=True)
-    os.environ["SPH_VARIANT"] = str(variant)
     ctx = sph.Context(prm, fluid, boundary, 0.0, -9.81)
+    ctx.set_variant(variant)
+    ctx.upload_state(fluid); ctx.eval_density(); ctx.eval_pressure(); ctx.eval_accel(0.0, -9.81)
     gb = ctx.read_boundary()
     gf = ctx.read_particles()
     gdu, gdv = ctx.read_accel()
@@ -46,6 +47,7 @@ def compare(tag, prm, fluid, boundary, variant, steps=0):
     print("   staged G3: max |da|/(sum|terms|+g) = %.2e" % np.max(da / (sa + 9.81)))
     if steps:
         ctx2 = sph.Context(prm, fluid, boundary, 0.0, -9.81)
+        ctx2.set_variant(variant)
         ctx2.step(steps)
         ctx2.sync()
         g2 = ctx2.read_particles()
@@ -58,9 +60,9 @@ def compare(tag, prm, fluid, boundary, variant, steps=0):
 
 
 def timing(tag, prm, fluid, boundary, variant, steps=200):
-    os.environ["SPH_VARIANT"] = str(variant)
     t0 = time.time()
     ctx = sph.Context(prm, fluid, boundary, 0.0, -9.81)
+    ctx.set_variant(variant)
     t1 = time.time()
     ctx.step(20); ctx.sync()
     t2 = time.time()

@@ -434,3 +434,60 @@ def test_wall_velocity_enters_the_viscosity_term(sph, orc, oracle, variant):
     odu, odv, sa = sum_abs_terms(oracle, box, fin, bpsi)
     assert np.max(np.hypot(du - odu, dv - odv) / (sa + G)) <= TOL
     assert np.max(np.hypot(odu - g["eval_du_2000"], odv - g["eval_dv_2000"])) > 1e-2    # the wall velocity matters
+
+
+def test_restart_from_read_back_continues_the_run(sph, orc):
+    """checkpoint / resume: sph_upload_state(sph_read_particles()) keeps du_dt, dv_dt aligned with their particles (the
+    reference's arrays are index-aligned, :616), so stepping on continues the uninterrupted run; a fresh context needs
+    sph_upload_accel as well.  Both against the uninterrupted run (summation order only: the re-bin reorders lists)."""
+    g = load_golden("block.npz")
+    box = tuple(g["box"])
+    prm, f, ctx = make_ctx(sph, orc, box, g["state"], g["boundary_xy"], 0)
+    b = boundary_particles(orc, g["boundary_xy"])
+    with ctx:
+        ctx.step(37, GX, GY)
+        ctx.sync()
+        snap = ctx.read_particles()
+        sdu, sdv = ctx.read_accel()
+        ctx.step(25, GX, GY)
+        ctx.sync()
+        ref = ctx.read_particles()
+    with sph.Context(prm, f, b, GX, GY) as c1:
+        c1.step(37, GX, GY)
+        c1.upload_state(c1.read_particles())            # re-bins; accelerations must follow their particles
+        du, dv = c1.read_accel()
+        assert np.max(np.abs(du - sdu)) <= 1e-3 * np.abs(sdu).max() and np.max(np.abs(dv - sdv)) <= 1e-3 * np.abs(sdv).max()
+        c1.step(25, GX, GY)
+        c1.sync()
+        got = c1.read_particles()
+    tol_x = 2e-5
+    assert max(np.abs(got["x"] - ref["x"]).max(), np.abs(got["y"] - ref["y"]).max()) <= tol_x
+    with sph.Context(prm, f, b, GX, GY) as c2:          # a different context restored from the checkpoint
+        c2.upload_state(snap)
+        c2.upload_accel(sdu, sdv)
+        du, dv = c2.read_accel()
+        assert np.array_equal(du, sdu) and np.array_equal(dv, sdv)
+        c2.step(25, GX, GY)
+        c2.sync()
+        got = c2.read_particles()
+    assert max(np.abs(got["x"] - ref["x"]).max(), np.abs(got["y"] - ref["y"]).max()) <= tol_x
+    # a scrambled du_dt would show as O(dt^2 |a|) = 1e-4 m after one step and far more after 25
+
+
+def test_time_kernel_needs_a_step(sph):
+    """sph_time_kernel(force) repeats the last step's kick: refused before the first step (it would kick twice)."""
+    prm, f, b = sph.scene("cfg0")
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        with pytest.raises(sph.SphError) as e:
+            ctx.time_kernel("force_kick", 2)
+        assert e.value.code == sph.SPH_E_STATE
+        assert ctx.time_kernel("density_eos", 2) > 0
+        ctx.step(3, GX, GY)
+        before = ctx.read_particles()
+        assert ctx.time_kernel("force_kick", 3) > 0
+        after = ctx.read_particles()
+        for k in ("x", "y", "u", "v", "rho"):
+            assert np.array_equal(before[k], after[k]), k      # idempotent on the live state
+        ctx.upload_state(before)
+        with pytest.raises(sph.SphError):
+            ctx.time_kernel("force_kick", 2)

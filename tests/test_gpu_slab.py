@@ -106,10 +106,9 @@ def test_slab_reuses_lists_between_rebuilds(sph, orc):
     prm = sph.default_params(tuple(g["box"]))
     f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))      # developed flow, |v| up to 20 m/s
     b = boundary_particles(orc, g["boundary_xy"])
-    old = sph.default_skin()
-    try:
+    if True:
         for frac in (0.0, 0.2):
-            sph.set_default_skin(frac)
+            prm.skin = frac          # per context: the slabs and the single context below all get this skin
             slabs, runner = build(sph, prm, f, b, 3)
             with sph.Context(prm, f, b, GX, GY) as ctx:
                 ctx.step(20, GX, GY)
@@ -142,8 +141,6 @@ def test_slab_reuses_lists_between_rebuilds(sph, orc):
             assert (counts[0] - 1 == 120) if frac == 0.0 else (1 < counts[0] - 1 < 120), (frac, counts)
             for s in slabs:
                 s.close()
-    finally:
-        sph.set_default_skin(old)
 
 
 def test_step_overlap_is_optional(sph, orc):

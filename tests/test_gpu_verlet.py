@@ -19,23 +19,12 @@ def m_fluid(prm):
     return np.float32(prm.rho0) * np.float32(prm.vol)
 
 
-@pytest.fixture
-def skin(sph):
-    """set the process-wide default skin for one test, restore it afterwards."""
-    old = sph.default_skin()
-
-    def _set(v):
-        sph.set_default_skin(v)
-    yield _set
-    sph.set_default_skin(old)
-
-
-def block_scene(sph, orc):
+def block_scene(sph, orc, skin=None):
     g = load_golden("block.npz")
     box = tuple(g["box"])
     xy = g["fluid_xy0"]
     state = np.concatenate([xy, np.zeros_like(xy)], 1)
-    prm = sph.default_params(box)
+    prm = sph.default_params(box, skin)       # the skin is a per-context parameter (sph_params.skin)
     return prm, particles(orc, state, m_fluid(prm)), boundary_particles(orc, g["boundary_xy"]), g
 
 
@@ -61,9 +50,8 @@ def lists_vs_exact_walk(ctx, tag):
 
 
 @pytest.mark.parametrize("frac", [0.05, 0.15, 0.4])
-def test_reused_lists_equal_exact_walk(sph, orc, skin, frac):
-    skin(frac)
-    prm, f, b, g = block_scene(sph, orc)
+def test_reused_lists_equal_exact_walk(sph, orc, frac):
+    prm, f, b, g = block_scene(sph, orc, frac)
     with sph.Context(prm, f, b, GX, GY) as ctx:
         rows, cols, cell = ctx.device_grid()
         assert abs(cell - 2 * prm.h * (1 + frac)) <= 1e-6
@@ -81,9 +69,8 @@ def test_reused_lists_equal_exact_walk(sph, orc, skin, frac):
         assert direct == 0
 
 
-def test_skin_zero_rebuilds_every_step(sph, orc, skin):
-    skin(0.0)
-    prm, f, b, g = block_scene(sph, orc)
+def test_skin_zero_rebuilds_every_step(sph, orc):
+    prm, f, b, g = block_scene(sph, orc, 0.0)
     with sph.Context(prm, f, b, GX, GY) as ctx:
         r0, _ = ctx.rebuild_stats()
         ctx.step(50, GX, GY)
@@ -95,11 +82,10 @@ def test_skin_zero_rebuilds_every_step(sph, orc, skin):
 
 
 @pytest.mark.parametrize("frac", [0.0, 0.15, 0.4])
-def test_trajectory_does_not_depend_on_skin(sph, orc, oracle, skin, frac):
+def test_trajectory_does_not_depend_on_skin(sph, orc, oracle, frac):
     """300 steps of the 14 400-particle dam break against the oracle, and the default scene against the golden
     trajectory (G5), under different skins."""
-    skin(frac)
-    prm, f, b, g = block_scene(sph, orc)
+    prm, f, b, g = block_scene(sph, orc, frac)
     box = tuple(g["box"])
     ob = boundary_particles(orc, g["boundary_xy"], g["psi"])
     of = oracle_block_300(oracle, orc, f, ob, box)
@@ -111,7 +97,7 @@ def test_trajectory_does_not_depend_on_skin(sph, orc, oracle, skin, frac):
     assert np.max(np.abs(got["rho"] - of["rho"]) / of["rho"]) <= 1e-3
 
     gd = load_golden("drop.npz")
-    prm = sph.default_params((0.0, 4.0, 0.0, 2.0))
+    prm = sph.default_params((0.0, 4.0, 0.0, 2.0), frac)
     f = particles(orc, gd["state_0"], m_fluid(prm))
     b = boundary_particles(orc, gd["boundary_xy"])
     with sph.Context(prm, f, b, GX, GY) as ctx:
@@ -126,7 +112,7 @@ def test_trajectory_does_not_depend_on_skin(sph, orc, oracle, skin, frac):
             assert dx <= tol, (frac, k, dx)
 
 
-def test_fast_random_particles(sph, orc, skin):
+def test_fast_random_particles(sph, orc):
     """random gas with velocities up to 40 m/s (c/10, the reference's design limit): particles cross a skin in a
     step or two, so rebuilds must be triggered on time; checked against the exact walk every few steps."""
     rng = np.random.default_rng(11)
@@ -142,7 +128,7 @@ def test_fast_random_particles(sph, orc, skin):
     f = particles(orc, state, m_fluid(prm))
     prm2, _, walls = sph.scene_disc(box, 8.0, 8.0, 0.1)
     for frac in (0.1, 0.3):
-        skin(frac)
+        prm.skin = frac
         with sph.Context(prm, f, walls, 0.0, 0.0) as ctx:
             for k in range(12):
                 ctx.step(3, 0.0, 0.0)
@@ -152,12 +138,12 @@ def test_fast_random_particles(sph, orc, skin):
             assert np.all(np.isfinite(got["x"])) and np.all(np.isfinite(got["rho"]))
 
 
-def test_coherent_motion_keeps_lists(sph, orc, oracle, skin):
+def test_coherent_motion_keeps_lists(sph, orc, oracle):
     """a block moving as a whole at 30 m/s (0.5 skin/2 per step at the default skin): the absolute criterion would
     rebuild every other step; the relative one (per-wave displacement boxes) keeps the lists for many steps.  Results
     against the oracle and against the exact walk as usual."""
-    skin(0.15)
     prm, f, b = sph.scene_block((0.0, 40.0, 0.0, 6.0), 2.0, 1.5, 160, 40)
+    prm.skin = 0.15
     f["u"] = 30.0
     p = oracle.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
     of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()

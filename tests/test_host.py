@@ -22,12 +22,12 @@ def test_abi_library_loads_and_exports_every_declared_symbol(sph):
     hdecl = set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", hheader))
     for name in hdecl:
         assert hasattr(H, name), name
-    assert L.sph_abi_version() == 2
+    assert L.sph_abi_version() == 3
 
 
 def test_struct_layouts(sph):
     assert sph.PARTICLE.itemsize == 28                       # struct particle :26-31
-    assert C.sizeof(sph.Params) == 15 * 4
+    assert C.sizeof(sph.Params) == 16 * 4
     assert C.sizeof(sph.KernelTimes) == 8 * 4 + 4 + 4 + 4
 
 
@@ -122,25 +122,26 @@ def test_create_argument_errors_and_no_cpu_fallback(sph):
     assert L.sph_step(None, 0.0, 0.0, 1) == sph.SPH_E_ARG
 
 
-def test_skin_setting_and_device_cell_are_host_only(sph):
-    """the skin (neighbour-structure reuse) is process-wide host state of the C ABI; slab hosts bin with 2H + skin."""
+def test_skin_is_a_per_context_parameter(sph):
+    """the skin (neighbour-structure reuse) is a field of sph_params, fixed per context; slab hosts bin with the
+    device cell 2H (1 + skin) of THEIR parameters (no process-wide state)."""
     L = sph.hip_lib()
-    old = sph.default_skin()
-    try:
-        assert 0.0 <= old <= 1.0
-        prm = sph.default_params()
-        two_h = np.float32(2) * np.float32(prm.h)
-        for frac in (0.0, 0.1, 0.4):
-            sph.set_default_skin(frac)
-            assert abs(sph.default_skin() - frac) < 1e-7
-            cell = np.float32(L.sph_device_cell(C.byref(prm)))
-            assert abs(cell - two_h * (1 + np.float32(frac))) <= 2e-7
-            assert sph.slab.device_cell(prm) == cell
-            # the slab partitioner bins with that cell
-            cols = sph.slab.grid_columns(prm)
-            assert cols == int((np.float32(prm.x_max) - np.float32(prm.x_min)) / cell) + 1
-        with pytest.raises(sph.SphError):
-            sph.set_default_skin(1.5)
-        assert L.sph_set_default_skin(C.c_float(-0.1)) == sph.SPH_E_ARG
-    finally:
-        sph.set_default_skin(old)
+    prm = sph.default_params()
+    assert abs(prm.skin - 0.15) < 1e-7
+    two_h = np.float32(2) * np.float32(prm.h)
+    for frac in (0.0, 0.1, 0.4):
+        prm.skin = frac
+        cell = np.float32(L.sph_device_cell(C.byref(prm)))
+        assert abs(cell - two_h * (1 + np.float32(frac))) <= 2e-7
+        assert sph.slab.device_cell(prm) == cell
+        # the slab partitioner bins with that cell
+        cols = sph.slab.grid_columns(prm)
+        assert cols == int((np.float32(prm.x_max) - np.float32(prm.x_min)) / cell) + 1
+    other = sph.default_params()                      # untouched by the loop above
+    assert abs(np.float32(L.sph_device_cell(C.byref(other))) - two_h * np.float32(1.15)) <= 2e-7
+    prm.skin = 1.5
+    assert L.sph_device_cell(C.byref(prm)) == 0.0      # invalid
+    _, f, b = sph.scene("cfg0")
+    with pytest.raises(sph.SphError) as e:
+        sph.Context(prm, f, b)
+    assert e.value.code == sph.SPH_E_ARG               # rejected before any device is touched
