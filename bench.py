@@ -147,6 +147,46 @@ def cpu_baseline(sph, name, nsteps=8, warm=2):
                       % (nsteps, warm, name, len(f), threads, model)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start one fresh process per GPU (this process has not
+    touched the GPU: no HIP call, no torch import), each with its own RANK / LOCAL_RANK, rendezvous on 127.0.0.1.
+    Rank 0's JSON line is forwarded; a failing rank fails the run.  (The torchrun form
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` works as well: the ranks then find
+    WORLD_SIZE in their environment and never come here.)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for k, pr in enumerate(procs):
+            if rcs[k] is None:
+                rcs[k] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs):      # one rank failed: the others would wait for it forever
+            for k, pr in enumerate(procs):
+                if rcs[k] is None:
+                    pr.kill()
+                    rcs[k] = pr.wait()
+        time.sleep(0.1)
+    out0.seek(0)
+    lines = [ln for ln in out0.read().decode(errors="replace").splitlines() if ln.startswith("{")]
+    if any(rcs) or not lines:
+        log("bench.py: ranks exited with", rcs)
+        return 1
+    os.write(1, (lines[-1] + "\n").encode())
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,16 +194,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary cfg1 measurement")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "rccl"), choices=["rccl", "host"],
+                    help="N > 1: halo transport. rccl = torch.distributed nccl backend (RCCL over xGMI), one GPU per "
+                         "rank; host = host-staged gloo (rehearsal: all ranks may share one device)")
+    ap.add_argument("--slabs-on-one-gpu", action="store_true",
+                    help="run the N = 1 workload through the slab path (one slab, no exchange): its overhead")
     args = ap.parse_args()
-    quiet_stdout()
 
     sph = importlib.import_module("pi-sph-fluid_amd")
     if not (os.path.exists(sph.LIB_HIP) and os.path.exists(sph.LIB_HOST)):
-        sph.build()
+        sph.build()      # before any rank starts
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    quiet_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or os.environ.get("SPH_FORCE_SLAB") == "1":
+    if args.gpus > 1 or world > 1 or args.slabs_on_one_gpu:
         from bench_slab import run_slabs          # one process per GPU over RCCL (torch.distributed)
         run_slabs(sph, args, emit)
         return

@@ -1,12 +1,17 @@
 """bench_slab.py — the N > 1 leg of bench.py: one process per GPU (torch.distributed, backend "nccl" = RCCL over
 xGMI), x-slab decomposition with one halo exchange per step (pi-sph-fluid_amd/slab.py, include/sph.h).
 
-Weak scaling: the cfg2 -> cfg3 family, one 4000 x 500 lattice block (2 000 000 particles, 1200 m of box) per GPU;
-`value` is the whole-job Mparticle-steps/s = N_fluid_total x timesteps/s / 1e6, timed over exactly K steps
-between barrier + device synchronisation, MAX over ranks.  SPH_SLAB_TRANSPORT=host selects a host-staged gloo
-transport (all ranks may then share one device; used to exercise this file on a 1-GPU box)."""
-import importlib
-import json
+Workloads
+  cfg2 (default)  weak scaling, the cfg2 -> cfg3 family: one 4000 x 500 lattice block (2 000 000 particles, 1200 m of
+                  box) per GPU; N = 4 is cfg3.  Constant gravity.
+  cfg3            the 8M dam break as BASELINE.json states it (any N; 4 slabs is the named configuration).
+  cfg4            32 000 000 particles, box 2400.6 x 150 m, gravity from the scripted tilt trace (sph_gravity: g(t) =
+                  G (sin th, -cos th), th = 15 deg sin(2 pi t / 8 s), re-sampled every 0.1 s of simulated time like the
+                  reference's 10 Hz poll, pi_sph_fluid.c:455-461).  Fixed total size: strong scaling.
+`value` is the whole-job Mparticle-steps/s = N_fluid_total x timesteps/s / 1e6, timed over exactly K steps between
+barrier + device synchronisation, MAX over ranks.  Every rank generates only the lattice columns it holds.
+--transport host selects a host-staged gloo transport (all ranks may then share one device; used to exercise this
+file on a 1-GPU box)."""
 import os
 import sys
 import time
@@ -56,48 +61,80 @@ class HostStagedTransport:
             self.slab.copy_in(1, self.rr.numpy().view(np.uint32))
 
 
+def workload_spec(sph, name, world):
+    """(label, block spec, scaling, gravity source or None)"""
+    if name in ("cfg2", "dam"):
+        spec = sph.dam_break_spec(world)
+        return ("dam break, %d x-slabs of 2 000 000 fluid particles (cfg2 family; N = 4 is cfg3)" % world, spec, "weak", None)
+    if name == "cfg3":
+        return ("cfg3: 8M dam break", sph.BLOCK_SCENES["cfg3"], "strong", None)
+    if name == "cfg4":
+        grav = sph.GravitySource(sph.GRAVITY_TILT, 9.81)      # 15 deg, 8 s, 0.1 s hold: the defaults of sph_gravity_init
+        return ("cfg4: 32M tank under the scripted tilt trace", sph.BLOCK_SCENES["cfg4"], "strong", grav)
+    raise ValueError("no slab workload %r" % name)
+
+
 def run_slabs(sph, args, emit):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    host_staged = os.environ.get("SPH_SLAB_TRANSPORT", "") == "host"
+    host_staged = args.transport == "host"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     ndev = torch.cuda.device_count()
     device = local_rank % max(ndev, 1)
-    torch.cuda.set_device(device)
+    if not host_staged and world > ndev:
+        raise SystemExit("bench.py: %d ranks need %d GPUs for the RCCL transport (found %d); use --transport host to "
+                         "rehearse on fewer" % (world, world, ndev))
+    if ndev:
+        torch.cuda.set_device(device)
     dist.init_process_group("gloo" if host_staged else "nccl", rank=rank, world_size=world)
 
-    prm, f, b = sph.dam_break(world)
-    n_total = len(f)
-    parts = sph.slab.partition_columns(prm, f, world)
+    label, spec, scaling, grav = workload_spec(sph, args.workload, world)
+    box, x0, y0, nx, ny = spec
+    prm = sph.default_params(box)
+    n_total = nx * ny
+    walls = sph.scene_walls(prm)
+    parts = sph.slab.partition_block(prm, spec, world)
     c0, c1 = parts[rank]
     t0 = time.time()
-    slab = sph.slab.GpuSlab(sph, prm, f, b, c0, c1, rank > 0, rank < world - 1, 0.0, -9.81, device=device)
-    del f
+    loc, ids = sph.slab.local_block_subset(sph, prm, spec, c0, c1)      # this rank's columns (+ 2 ghost columns) only
+    g0 = grav.sample(0.0) if grav else (0.0, -9.81)
+    slab = sph.slab.GpuSlab(sph, prm, None, walls, c0, c1, rank > 0, rank < world - 1, g0[0], g0[1], device=device,
+                            local=(loc, ids))
+    del loc, ids
+    dt_sim = float(np.float32(prm.dt))
     stream = torch.cuda.Stream(device=device)
-    gx, gy = 0.0, -9.81
+    sim_step = [0]
+
+    def gravity(_k):
+        """the gravity vector of the next step (:632 re-reads g every step)"""
+        sim_step[0] += 1
+        return grav.sample(sim_step[0] * dt_sim) if grav else (0.0, -9.81)
+
     with torch.cuda.stream(stream):
         slab.set_stream(stream.cuda_stream)          # kernels and RCCL ops are ordered through torch's current stream
         transport = (HostStagedTransport(torch, dist, slab, rank, world) if host_staged
                      else sph.slab.TorchTransport(torch, dist, slab, rank, world, torch.device("cuda", device)))
         runner = sph.slab.SlabRunner(slab, transport)
-        log(rank, "slab columns [%d,%d) created in %.2fs, local/owned = %s" % (c0, c1, time.time() - t0, slab.counts()))
-        runner.step(args.warmup, gx, gy)
+        log(rank, "slab columns [%d,%d) of %d created in %.2fs, local/owned = %s" %
+            (c0, c1, sph.slab.grid_columns(prm), time.time() - t0, slab.counts()))
+        runner.step(args.warmup, gravity=gravity)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        runner.step(args.steps, gx, gy)
+        runner.step(args.steps, gravity=gravity)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         slab.sync()                                   # raises on capacity / out-of-domain / NaN
         n_loc, n_own = slab.counts()
+        rebuilds = slab.rebuilds()
     tmax = torch.tensor([dt], dtype=torch.float64)
     owned = torch.tensor([n_own], dtype=torch.int64)
     if not host_staged:
@@ -108,21 +145,23 @@ def run_slabs(sph, args, emit):
     if rank == 0:
         steps_per_s = args.steps / dt
         value = steps_per_s * n_total / 1e6
+        step_gbs = sph.STEP_ALGO_BYTES * n_total * steps_per_s / 1e9 / world
         out = {
             "metric": "SPH Mparticle-steps/sec (N_fluid x timesteps/sec / 1e6)",
             "value": round(value, 2), "unit": "Mparticle-steps/s", "timesteps_per_s": round(steps_per_s, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "dam break, %d x-slabs of 2 000 000 fluid particles (cfg2 family; N = 4 is cfg3): "
-                                   "%d fluid + %d boundary particles, box %d x 60 m" % (world, n_total, len(b), 1200 * world),
-                       "n_fluid": n_total, "n_boundary": len(b),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d fluid + %d boundary particles, box %g x %g m%s" %
+                                   (label, n_total, len(walls), box[1] - box[0], box[3] - box[2],
+                                    ", gravity = scripted tilt trace (15 deg, 8 s period, 0.1 s hold)" if grav else ""),
+                       "n_fluid": n_total, "n_boundary": len(walls),
                        "parallelism": "%d x-slabs, 2-column halo + migration in one RCCL send/recv pair per neighbour per step%s"
                                       % (world, " (host-staged gloo transport)" if host_staged else "")},
             "particles_conserved": int(owned.item()) == n_total,
-            "roofline": {"bound": "hbm", "achieved": round(sph.STEP_ALGO_BYTES * n_total * steps_per_s / 1e9 / world, 1),
+            "neighbour_rebuilds_per_step": round(rebuilds / max(args.steps + args.warmup, 1), 4),
+            "roofline": {"bound": "hbm", "achieved": round(step_gbs, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU (whole step, 152 B per particle-step)",
-                         "frac": round(sph.STEP_ALGO_BYTES * n_total * steps_per_s / 1e9 / world / HBM_PEAK_GBS, 4),
-                         "traffic": None},
+                         "frac": round(step_gbs / HBM_PEAK_GBS, 4), "traffic": None},
         }
         emit(out)
     dist.barrier()

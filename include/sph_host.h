@@ -38,6 +38,10 @@ long sph_scene_disc(const sph_params *prm, float cx, float cy, float radius, sph
 /* nx x ny lattice block with its lower-left particle at (x0,y0), x = x0 + i*R (i outer, j inner):
  * the dam-break scenes (cfg2-4). */
 long sph_scene_block(const sph_params *prm, float x0, float y0, long nx, long ny, sph_particle *out, long cap);
+/* lattice columns [i_begin, i_end) of the same block, bit-identical to the corresponding part of sph_scene_block
+ * (particle k of the range is particle i_begin*ny + k of the block): a slab host generates only what it holds. */
+long sph_scene_block_range(const sph_params *prm, float x0, float y0, long nx, long ny, long i_begin, long i_end,
+                           sph_particle *out, long cap);
 
 /* ---- gravity source: get_gravity / get_gravity_routine (:431-464) ---- */
 typedef enum sph_gravity_kind {

@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",
+    "sph_scene_block_range",
     "sph_gravity_init", "sph_gravity_sample",
 ]
 
@@ -177,6 +178,8 @@ def host_lib():
         L.sph_scene_disc.restype = cl
         L.sph_scene_block.argtypes = [C.POINTER(Params), cf, cf, cl, cl, vp, cl]
         L.sph_scene_block.restype = cl
+        L.sph_scene_block_range.argtypes = [C.POINTER(Params), cf, cf, cl, cl, cl, cl, vp, cl]
+        L.sph_scene_block_range.restype = cl
         L.sph_gravity_init.argtypes = [C.POINTER(Gravity), C.c_int, cf]
         L.sph_gravity_init.restype = None
         L.sph_gravity_sample.argtypes = [C.POINTER(Gravity), cf, C.POINTER(cf), C.POINTER(cf)]
@@ -215,6 +218,11 @@ def scene_default(prm=None):
     return prm, _two_call(L.sph_scene_default_fluid, C.byref(prm)), _two_call(L.sph_scene_walls, C.byref(prm), 1)
 
 
+def scene_walls(prm, accumulate=False):
+    """the wall generator of :523-540 for the box of prm (single layer, spacing R)."""
+    return _two_call(host_lib().sph_scene_walls, C.byref(prm), 1 if accumulate else 0)
+
+
 def scene_disc(box, cx, cy, radius):
     prm = default_params(box)
     L = host_lib()
@@ -225,6 +233,23 @@ def scene_block(box, x0, y0, nx, ny):
     prm = default_params(box)
     L = host_lib()
     return prm, _two_call(L.sph_scene_block, C.byref(prm), x0, y0, nx, ny), _two_call(L.sph_scene_walls, C.byref(prm), 0)
+
+
+def block_range(prm, x0, y0, nx, ny, i_begin, i_end):
+    """lattice columns [i_begin, i_end) of the nx x ny block (bit-identical to that part of scene_block)."""
+    return _two_call(host_lib().sph_scene_block_range, C.byref(prm), x0, y0, nx, ny, i_begin, i_end)
+
+
+# the dam-break family as (box, x0, y0, nx, ny): what a slab host needs to generate only its own columns
+BLOCK_SCENES = {
+    "cfg2": ((0.0, 1200.0, 0.0, 60.0), 0.3, 0.3, 4000, 500),
+    "cfg3": ((0.0, 2400.0, 0.0, 60.0), 0.3, 0.3, 16000, 500),
+    "cfg4": ((0.0, 2400.6, 0.0, 150.0), 0.3, 0.3, 32000, 1000),
+}
+
+
+def dam_break_spec(n_slabs):
+    return ((0.0, 1200.0 * n_slabs, 0.0, 60.0), 0.3, 0.3, 4000 * n_slabs, 500)
 
 
 def scene(name):

@@ -96,12 +96,17 @@ long sph_scene_disc(const sph_params *p, float cx, float cy, float radius, sph_p
 }
 
 long sph_scene_block(const sph_params *p, float x0, float y0, long nx, long ny, sph_particle *out, long cap) {
-    if (!p || nx < 0 || ny < 0) return SPH_E_ARG;
-    if (!out) return nx * ny;
-    if (nx * ny > cap) return SPH_E_ARG;
+    return sph_scene_block_range(p, x0, y0, nx, ny, 0, nx, out, cap);
+}
+
+long sph_scene_block_range(const sph_params *p, float x0, float y0, long nx, long ny, long i_begin, long i_end,
+                           sph_particle *out, long cap) {
+    if (!p || nx < 0 || ny < 0 || i_begin < 0 || i_end > nx || i_begin > i_end) return SPH_E_ARG;
+    if (!out) return (i_end - i_begin) * ny;
+    if ((i_end - i_begin) * ny > cap) return SPH_E_ARG;
     const float m = p->rho0 * p->vol;
     long n = 0;
-    for (long i = 0; i < nx; i++) {
+    for (long i = i_begin; i < i_end; i++) {
         float x = x0 + (float)i * p->r;
         for (long j = 0; j < ny; j++) {
             float y = y0 + (float)j * p->r;

@@ -57,16 +57,9 @@ def grid_rows(prm):
     return int((np.float32(prm.y_max) - np.float32(prm.y_min)) / device_cell(prm)) + 1
 
 
-def partition_columns(prm, fluid, world, slack=64):
-    """[(c0, c1)] * world: contiguous column ranges holding ~equal numbers of particles.  Columns outside
-    [first occupied - slack, last occupied + slack] belong to no slab (a particle reaching them is reported
-    as out of domain), which keeps every local grid proportional to its fluid instead of to the dry box."""
-    cols = grid_columns(prm)
-    gc = np.clip(global_columns(prm, fluid["x"]), 0, cols - 1)
-    hist = np.bincount(gc, minlength=cols)
-    occ = np.nonzero(hist)[0]
-    lo = max(0, int(occ[0]) - slack)
-    hi = min(cols, int(occ[-1]) + 1 + slack)
+def _cuts_from_histogram(hist, world, lo, hi):
+    """column boundaries [lo = cuts[0] < ... < cuts[world] = hi] at the quantiles of the per-column histogram, every
+    slab at least 4 columns wide."""
     cum = np.cumsum(hist)
     total = int(cum[-1])
     cuts = [lo]
@@ -81,6 +74,51 @@ def partition_columns(prm, fluid, world, slack=64):
     if any(cuts[r + 1] - cuts[r] < 4 for r in range(world)) or cuts[0] < 0:
         raise ValueError("scene too narrow for %d slabs" % world)
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def partition_columns(prm, fluid, world, slack=None):
+    """[(c0, c1)] * world: contiguous column ranges holding ~equal numbers of particles.  By default the slabs tile
+    the whole box: the first begins at column 0 and the last ends at the box edge, so a dam-break front can run
+    through the dry part of the box without ever leaving the decomposition (the cells of a dry column cost 12 bytes
+    each and the scan skips them).  slack = k restricts the decomposition to [first occupied - k, last occupied + k]
+    (small local grids for tests; a particle leaving that range is reported as out of domain)."""
+    cols = grid_columns(prm)
+    gc = np.clip(global_columns(prm, fluid["x"]), 0, cols - 1)
+    hist = np.bincount(gc, minlength=cols)
+    occ = np.nonzero(hist)[0]
+    lo = 0 if slack is None else max(0, int(occ[0]) - slack)
+    hi = cols if slack is None else min(cols, int(occ[-1]) + 1 + slack)
+    return _cuts_from_histogram(hist, world, lo, hi)
+
+
+def block_lattice_columns(prm, spec):
+    """global cell column of every lattice column i of a block scene spec = (box, x0, y0, nx, ny): x_i = x0 + i R in
+    f32, exactly as sph_scene_block computes it."""
+    _, x0, _, nx, _ = spec
+    xi = np.float32(x0) + np.arange(nx, dtype=np.float32) * np.float32(prm.r)
+    return global_columns(prm, xi)
+
+
+def partition_block(prm, spec, world):
+    """partition_columns for a lattice block without generating it (per-column counts follow from the lattice)."""
+    ny = spec[4]
+    cols = grid_columns(prm)
+    hist = np.bincount(np.clip(block_lattice_columns(prm, spec), 0, cols - 1), minlength=cols) * ny
+    return _cuts_from_histogram(hist, world, 0, cols)
+
+
+def local_block_subset(pkg, prm, spec, c0, c1):
+    """the particles of a block scene inside columns [c0 - 2, c1 + 2) and their global ids, generating only those
+    lattice columns (sph_scene_block_range): what local_subset(prm, scene_block(...), c0, c1) would return."""
+    _, x0, y0, nx, ny = spec
+    gc = block_lattice_columns(prm, spec)
+    sel = np.nonzero((gc >= c0 - GHOST) & (gc < c1 + GHOST))[0]
+    if len(sel) == 0:
+        return np.zeros(0, pkg.PARTICLE), np.zeros(0, np.uint32)
+    i0, i1 = int(sel[0]), int(sel[-1]) + 1                 # lattice columns are monotone in x: a contiguous range
+    loc = pkg.block_range(prm, x0, y0, nx, ny, i0, i1)
+    ids = (np.arange(i0 * ny, i1 * ny, dtype=np.int64)).astype(np.uint32)
+    return loc, ids
 
 
 def local_subset(prm, fluid, c0, c1):
@@ -102,10 +140,13 @@ class GpuSlab:
     """One slab on one GPU through the C ABI (sph_create_slab ...)."""
 
     def __init__(self, pkg, prm, fluid, boundary_all, c0, c1, has_left, has_right, gx=0.0, gy=-9.81, device=0,
-                 halo_capacity=0, particle_capacity=0):
+                 halo_capacity=0, particle_capacity=0, local=None):
+        """fluid = the whole scene (the slab keeps its part), or None with local = (particles, global ids) of the
+        columns [c0 - 2, c1 + 2) when the host generated only those."""
         self.pkg, self.L = pkg, pkg.hip_lib()
         self.c0, self.c1 = c0, c1
-        loc, ids = local_subset(prm, fluid, c0, c1)
+        loc, ids = local if local is not None else local_subset(prm, fluid, c0, c1)
+        loc, ids = np.ascontiguousarray(loc, pkg.PARTICLE), np.ascontiguousarray(ids, np.uint32)
         self.halo_capacity = halo_capacity or default_halo_capacity(prm)
         self.particle_capacity = particle_capacity or (len(loc) + len(loc) // 4 + 2 * self.halo_capacity + 1024)
         desc = pkg.SlabDesc(c0, c1, int(has_left), int(has_right), self.halo_capacity, self.particle_capacity)
@@ -207,6 +248,12 @@ class GpuSlab:
         self._chk(self.L.sph_slab_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def rebuilds(self):
+        """rebuilds of the neighbour structure since creation (the same number on every slab)."""
+        a, b = C.c_longlong(), C.c_longlong()
+        self._chk(self.L.sph_rebuild_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value
+
 
 class LocalTransport:
     """All slabs live in this process (one device): what slab r sends right is what slab r+1 receives left."""
@@ -280,8 +327,12 @@ class SlabRunner:
         # splitting the density pass costs one more launch: worth it only when there is an exchange to hide
         self.overlap = (len(self.slabs) > 1 or getattr(transport, "world", 1) > 1) if overlap is None else overlap
 
-    def step(self, nsteps=1, gx=0.0, gy=-9.81):
-        for _ in range(nsteps):
+    def step(self, nsteps=1, gx=0.0, gy=-9.81, gravity=None):
+        """gravity: optional callable k -> (gx, gy) sampled before every step (the reference re-reads g every step,
+        :632); otherwise the constant (gx, gy)."""
+        for k in range(nsteps):
+            if gravity is not None:
+                gx, gy = gravity(k)
             for s in self.slabs:
                 s.step_begin(gx, gy)
             self.transport.reduce_flag()

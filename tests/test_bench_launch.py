@@ -1,0 +1,41 @@
+"""bench.py --gpus N starts its own ranks (no torchrun needed) and never hangs: one process per rank, rendezvous on
+127.0.0.1, rank 0's JSON line forwarded, a failing rank fails the whole run.
+
+CPU (no GPU in the container): the ranks rendezvous over gloo, then slab creation fails LOUDLY (the product has no CPU
+path) and the launcher returns non-zero within seconds.  GPU box: two ranks share the one MI355X through the host-staged
+transport and the run conserves every particle."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+from conftest import ROOT
+
+CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "6", "--warmup", "3"]
+
+
+def test_self_launch_fails_loudly_without_gpu(sph):
+    if sph.hip_lib().sph_device_count() > 0:
+        pytest.skip("a GPU is present: covered by test_self_launch_two_ranks_on_one_gpu")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run(CMD, capture_output=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert b"no HIP device" in r.stderr and b"no CPU path" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]      # no result line
+    assert time.time() - t0 < 300                                                       # and no rendezvous hang
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_on_one_gpu(sph):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(CMD, capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["particles_conserved"] is True
+    assert out["config"]["n_fluid"] == 4000000 and out["value"] > 0 and out["scaling"] == "weak"

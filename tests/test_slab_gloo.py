@@ -68,8 +68,18 @@ def test_partition_and_halo_format(sph):
         counts = [int(((gc >= a) & (gc < z)).sum()) for a, z in parts]
         assert sum(counts) == len(f) and max(counts) - min(counts) <= 0.02 * len(f) / world + 1500
         assert all(z - a >= 4 for a, z in parts)
-    # dry part of the box beyond the slack belongs to no slab
-    assert parts[-1][1] < sph.slab.grid_columns(prm)
+    # the slabs tile the whole box (a dam-break front never leaves the decomposition) ...
+    assert parts[0][0] == 0 and parts[-1][1] == sph.slab.grid_columns(prm)
+    # ... unless a slack is given (small local grids): then the dry part beyond it belongs to no slab
+    tight = sph.slab.partition_columns(prm, f, 4, slack=64)
+    assert tight[-1][1] < sph.slab.grid_columns(prm)
+    # a lattice block is partitioned without generating it, and a slab host generates only its own columns
+    spec = sph.dam_break_spec(1)
+    assert sph.slab.partition_block(prm, spec, 8) == parts
+    c0, c1 = parts[3]
+    loc, ids = sph.slab.local_block_subset(sph, prm, spec, c0, c1)
+    ref_loc, ref_ids = sph.slab.local_subset(prm, f, c0, c1)
+    assert np.array_equal(ids, ref_ids) and loc.tobytes() == ref_loc.tobytes()
     assert sph.slab.halo_words(10) == 4 + 5 * 10
     with pytest.raises(ValueError):
         sph.slab.partition_columns(*sph.scene("cfg0")[:2], 8)
