@@ -346,6 +346,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.skey, n); ALLOC(a.pos_ref, n);
     const size_t ntiles = (n + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES + 9;
     ALLOC(a.tiles, TILE_WORDS * ntiles); ALLOC(a.nlist, (size_t)LIST_WORDS_PER_TILE * ntiles);
+    ALLOC(a.wbase, ntiles * SPH_TILE_PARTICLES); ALLOC(a.stab, (size_t)STAB_ENTRIES_PER_TILE * ntiles);
+    ALLOC(a.xranges, (size_t)XRANGE_WORDS * ntiles);
     const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / BOXG);      // box groups
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     ALLOC(a.slot, n > nb ? n : nb);

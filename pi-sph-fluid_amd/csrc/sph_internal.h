@@ -62,7 +62,10 @@ struct Arrays {
     uint32_t *skey;    // sorted cell keys
     float2 *pos_ref;   // x,y at the last rebuild (the positions the neighbour lists were built from)
     uint32_t *tiles;   // one TILE_WORDS-word TileInfo record per 256-particle workgroup (sph_list.inc)
-    uint32_t *nlist;   // neighbour lists: per tile LROWS2 rows x 256 lanes of 2 x 16-bit entries (sph_list.inc)
+    uint32_t *nlist;   // neighbour lists: per tile LROWS4 rows x 256 lanes of 4 x 8-bit entries (sph_list.inc)
+    unsigned short *wbase; // per particle: first LDS slot of its candidate window (list entries are relative to it)
+    uint32_t *xranges;     // per tile XRANGE_WORDS: range table of the tiles with more than 6 candidate ranges
+    unsigned short *stab;  // staging table: per tile STAB_ENTRIES_PER_TILE LDS slots, one per staged candidate
     // staging (T)
     float4 *pk;        // x, y, id bits, cell key bits (after kick/drift, before the sort)
     float2 *velt;      // u,v after the second half kick, sorted order: the velocity between steps (vel: after the first)
@@ -108,7 +111,7 @@ enum {
     FLAG_LATCH = 11,        // slab mode: the reduced rebuild word of this step, latched by k_halo_in for the final density pass
     FLAG_COUNT = 12
 };
-constexpr int TILE_WORDS = 16;           // 32-bit words per tile record
+constexpr int TILE_WORDS = 32;           // 32-bit words per tile record
 constexpr int WNBR_WORDS = 10;           // words per box group in Arrays::wnbr
 #ifndef SPH_BOX_GROUP
 #define SPH_BOX_GROUP 64                 // consecutive sorted particles per displacement box (power of two, <= 64;
@@ -118,7 +121,9 @@ constexpr int BOXG = SPH_BOX_GROUP;
 #ifndef SPH_TILE_PARTICLES
 #define SPH_TILE_PARTICLES 256           // particles per tile (= threads per workgroup of the list kernels)
 #endif
-constexpr int LIST_WORDS_PER_TILE = 24 * SPH_TILE_PARTICLES;   // LROWS2 x TP (sph_list.inc static_asserts this)
+constexpr int LIST_WORDS_PER_TILE = 12 * SPH_TILE_PARTICLES;   // LROWS4 x TP (sph_list.inc static_asserts this)
+constexpr int XRANGE_WORDS = 100;                              // 3 RMAX + 1 prefix sums, 3 RMAX first particles (sph_list.inc)
+constexpr int STAB_ENTRIES_PER_TILE = 1280;                    // staging-table entries per tile (sph_list.inc)
 constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle list padding points at (finite: no NaN)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record
