@@ -72,7 +72,7 @@ def main():
         lines.append("")
     # per-launch HBM traffic of the step kernels in bench.py's naming (read side doubled, see above)
     names = {"k_kick_drift<false>": "kick_drift", "k_key_hist<false>": "key_hist", "k_reorder": "reorder",
-             "k_build_list": "build_list", "k_density_list<1>": "density_eos", "k_force_list<2, 0>": "force_kick", "k_check": "check",
+             "k_build_list": "build_list", "k_density_list<1, 0>": "density_eos", "k_force_list<2, 0>": "force_kick", "k_check": "check",
              "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply"}
     traffic = {}
     for kn, bn in names.items():
