@@ -47,8 +47,8 @@ struct sph_ctx {
     bool primed = false;
     bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};          // [0,1]: one step; [2,3]: MULTI_STEPS steps
+    hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
     bool use_graph = true;
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
     long long oob_total = 0, nan_total = 0;
@@ -165,7 +165,7 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
 }
 
 void drop_graph(sph_ctx *ctx) {
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 4; k++) {
         if (ctx->gexec[k]) { (void)hipGraphExecDestroy(ctx->gexec[k]); ctx->gexec[k] = nullptr; }
         if (ctx->graph[k]) { (void)hipGraphDestroy(ctx->graph[k]); ctx->graph[k] = nullptr; }
     }
@@ -183,6 +183,35 @@ hipGraphExec_t step_graph(sph_ctx *ctx) {
         return nullptr;
     }
     enqueue_step_body(ctx, nullptr);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &ctx->graph[k]);
+    if (e == hipSuccess) e = hipGraphInstantiate(&ctx->gexec[k], ctx->graph[k], nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        drop_graph(ctx);
+        ctx->use_graph = false;
+        return nullptr;
+    }
+    return ctx->gexec[k];
+}
+
+// MULTI_STEPS consecutive steps of the fused (primed) loop as ONE graph: a replay has a fixed cost of several
+// microseconds whatever it holds, and sph_step(nsteps) usually asks for many steps.  An even number of steps leaves the
+// orientation of the two position / velocity sets as it was.
+constexpr int MULTI_STEPS = 8;
+hipGraphExec_t multi_graph(sph_ctx *ctx) {
+    if (!ctx->use_graph) return nullptr;
+    const int k = 2 + (ctx->a.pos == ctx->pos_a ? 0 : 1);
+    if (ctx->gexec[k]) return ctx->gexec[k];
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->use_graph = false;
+        return nullptr;
+    }
+    for (int s = 0; s < MULTI_STEPS; s++) {
+        std::swap(ctx->a.pos, ctx->a.pos2);
+        std::swap(ctx->a.vel, ctx->a.vel2);
+        enqueue_step_body(ctx, nullptr);
+    }
     hipError_t e = hipStreamEndCapture(ctx->stream, &ctx->graph[k]);
     if (e == hipSuccess) e = hipGraphInstantiate(&ctx->gexec[k], ctx->graph[k], nullptr, nullptr, 0);
     if (e != hipSuccess) {
@@ -484,9 +513,19 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_step_begin / exchange / sph_slab_step_end");
     (void)hipSetDevice(ctx->device);
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
-    for (int s = 0; s < nsteps; s++) {
+    int s = 0;
+    while (s < nsteps) {
+        if (fused(ctx) && ctx->primed && nsteps - s >= MULTI_STEPS) {
+            hipGraphExec_t g = multi_graph(ctx);
+            if (g) {
+                HIPCHK(ctx, hipGraphLaunch(g, ctx->stream));
+                s += MULTI_STEPS;
+                continue;
+            }
+        }
         int rc = run_step(ctx, nullptr);
         if (rc) return rc;
+        s++;
     }
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;

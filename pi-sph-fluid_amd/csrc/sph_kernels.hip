@@ -26,6 +26,9 @@ namespace sph {
 #define DEV __device__ __forceinline__
 
 constexpr int BLK = 256;   // 4 waves of 64
+// grid of a kernel that returns at once in most steps (the rebuild kernels): small, striding over its work
+constexpr int GATED_GRID_MAX = 2048;
+static inline int gated_grid(int work_blocks) { return work_blocks < GATED_GRID_MAX ? (work_blocks > 0 ? work_blocks : 1) : GATED_GRID_MAX; }
 
 DEV bool finite_bits(float x) { return (__float_as_uint(x) & 0x7fffffffu) < 0x7f800000u; }
 
@@ -185,8 +188,8 @@ DEV void key_hist_body(const Consts &c, const float2 *__restrict__ pos, const ui
                        const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs, float2 *__restrict__ velk,
                        float4 *__restrict__ pk, uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
                        uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags, uint32_t *__restrict__ dn,
-                       uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r) {
-    const int t = blockIdx.x * BLK + threadIdx.x;
+                       uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r, int chunk) {
+    const int t = chunk * BLK + threadIdx.x;      // chunk = 256 consecutive array slots
     const int lane = threadIdx.x & 63;
     int src0 = 0, n;
     if (SLAB) {
@@ -248,9 +251,13 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
                                                   float2 *__restrict__ velk, float4 *__restrict__ pk,
                                                   uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
                                                   uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
-                                                  const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn) {
+                                                  const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
+                                                  int nchunks) {
     if (*rebuild == 0u) return;      // rebuild kernel
-    key_hist_body<false>(c, pos, id, vsrc, cs, velk, pk, slot, count, dirty, flags, dn, nullptr, nullptr);
+    // a small grid striding over the chunks: in most steps this launch returns at once, and what that costs grows with
+    // the grid (1.5 us up to 2048 workgroups, 2.8 us at 8192: tools/ubench_launch)
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x)
+        key_hist_body<false>(c, pos, id, vsrc, cs, velk, pk, slot, count, dirty, flags, dn, nullptr, nullptr, chunk);
 }
 
 // the pair part of criterion (1): one thread per box group, against every group k_build_list listed for it
@@ -302,8 +309,9 @@ void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
 
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc) {
     if (cap <= 0) return;
-    hipLaunchKernelGGL(k_key_hist, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.pos, a.id, vsrc, a.cell_start, a.velk,
-                       a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn);
+    const int nchunks = (cap + BLK - 1) / BLK;
+    hipLaunchKernelGGL(k_key_hist, dim3(gated_grid(nchunks)), dim3(BLK), 0, st, c, a.pos, a.id, vsrc, a.cell_start, a.velk,
+                       a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, nchunks);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(BLK) void k_halo_out(Consts c, const float2 *__rest
                                                   int part_blocks, int halo_blocks) {
     if (*rebuild != 0u) {
         if ((int)blockIdx.x < part_blocks)
-            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r);
+            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r, (int)blockIdx.x);
     } else if ((int)blockIdx.x < 2 * halo_blocks) {
         const int side = (int)blockIdx.x / halo_blocks;
         pack_update_body(c, side, ((int)blockIdx.x - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, send_l, send_r);
@@ -582,22 +590,23 @@ __global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, 
                                                  uint32_t *__restrict__ id, uint32_t *__restrict__ skey,
                                                  const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild) {
     if (*rebuild == 0u) return;
-    int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= (int)dn[0]) return;
-    float4 q = pk[i];
-    const uint32_t key = __float_as_uint(q.w);
-    uint32_t dst = cell_start[key] + slot[i];
-    pos[dst] = make_float2(q.x, q.y);
-    pos_ref[dst] = make_float2(q.x, q.y);
-    vel[dst] = velk[i];
-    id[dst] = __float_as_uint(q.z);
-    skey[dst] = key;        // sorted keys: tile records, and the sort cell of a particle between rebuilds
+    const int n = (int)dn[0];
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {      // small grid: see k_key_hist
+        float4 q = pk[i];
+        const uint32_t key = __float_as_uint(q.w);
+        uint32_t dst = cell_start[key] + slot[i];
+        pos[dst] = make_float2(q.x, q.y);
+        pos_ref[dst] = make_float2(q.x, q.y);
+        vel[dst] = velk[i];
+        id[dst] = __float_as_uint(q.z);
+        skey[dst] = key;        // sorted keys: tile records, and the sort cell of a particle between rebuilds
+    }
 }
 
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     (void)c;
     if (cap <= 0) return;
-    hipLaunchKernelGGL(k_reorder, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, a.pk, a.velk, a.slot, a.cell_start, a.pos,
+    hipLaunchKernelGGL(k_reorder, dim3(gated_grid((cap + BLK - 1) / BLK)), dim3(BLK), 0, st, a.pk, a.velk, a.slot, a.cell_start, a.pos,
                        a.pos_ref, a.vel, a.id, a.skey, a.dn, a.rebuild);
 }
 
