@@ -58,9 +58,11 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
-def run_single(sph, name, steps, warmup, profile_steps=20):
+def run_single(sph, name, steps, warmup, profile_steps=20, skin=None):
     """K timed steps of one scene on device 0; returns a result dict."""
     prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
+    if skin is not None:
+        prm.skin = skin
     n = len(f)
     t0 = time.time()
     ctx = sph.Context(prm, f, b, 0.0, -9.81, device=0)
@@ -198,6 +200,7 @@ def main():
     ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "rccl"), choices=["rccl", "host"],
                     help="N > 1: halo transport. rccl = torch.distributed nccl backend (RCCL over xGMI), one GPU per "
                          "rank; host = host-staged gloo (rehearsal: all ranks may share one device)")
+    ap.add_argument("--skin", type=float, default=None, help="Verlet skin as a fraction of 2H (default: the library's)")
     ap.add_argument("--slabs-on-one-gpu", action="store_true",
                     help="run the N = 1 workload through the slab path (one slab, no exchange): its overhead")
     args = ap.parse_args()
@@ -216,7 +219,7 @@ def main():
         run_slabs(sph, args, emit)
         return
 
-    res = run_single(sph, args.workload, args.steps, args.warmup)
+    res = run_single(sph, args.workload, args.steps, args.warmup, skin=args.skin)
     log("primary:", json.dumps(res))
     out = {
         "metric": "SPH Mparticle-steps/sec (N_fluid x timesteps/sec / 1e6)",
@@ -237,7 +240,7 @@ def main():
         "roofline": roofline(sph, res),
     }
     if not args.no_also and args.workload != "cfg1":
-        r1 = run_single(sph, "cfg1", max(args.steps, 1), args.warmup)
+        r1 = run_single(sph, "cfg1", max(args.steps, 1), args.warmup, skin=args.skin)
         log("also:", json.dumps(r1))
         out["also"] = [{"workload": "cfg1: %d fluid + %d boundary, drop on dry surface, box 409.6 x 204.8 m" %
                         (r1["n_fluid"], r1["n_boundary"]),
@@ -250,7 +253,7 @@ def main():
         # the same scene once the flow is developed (splashes, |v| ~ 25 m/s): the neighbour structure is rebuilt three
         # times as often as in the headline window
         late_warm = 4000
-        r2 = run_single(sph, "cfg2", max(args.steps, 1), late_warm)
+        r2 = run_single(sph, "cfg2", max(args.steps, 1), late_warm, skin=args.skin)
         log("also:", json.dumps(r2))
         out["also"].append({"workload": "cfg2, developed flow: steps %d-%d of the same run" % (late_warm, late_warm + args.steps),
                             "value": round(r2["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",

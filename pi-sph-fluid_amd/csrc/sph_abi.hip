@@ -45,6 +45,7 @@ struct sph_ctx {
     // that look-ahead (false after creation / upload / eval_accel / variant change: the next step then starts with
     // the stand-alone kick/drift kernel instead).  One captured graph per orientation of the two sets.
     bool primed = false;
+    bool velt_stale = false;     // the fused force pass does not store the velocity between steps: refresh_velt() before use
     bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
     hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};          // [0,1]: one step; [2,3]: MULTI_STEPS steps
@@ -143,6 +144,12 @@ size_t padded_items(const Consts &c) {
 
 bool fused(const sph_ctx *ctx) { return ctx->variant == 0; }
 
+// the velocity after the second half kick (:638-639): the fused step leaves it to be recomputed on demand
+void refresh_velt(sph_ctx *ctx) {
+    if (ctx->velt_stale) launch_refresh_velt(ctx->stream, ctx->c, ctx->a, ctx->cap);
+    ctx->velt_stale = false;
+}
+
 // What a step launches after its kick/drift (SPH_K_* order; ev != nullptr records an event before each): the rebuild
 // kernels (no-ops unless requested), density + EOS, force + kick.  With the list kernels the force pass also
 // integrates the next step's kick 1/2 + drift (FORCE_KICK_DRIFT).
@@ -232,9 +239,11 @@ int run_step(sph_ctx *ctx, hipEvent_t *ev) {
         std::swap(ctx->a.pos, ctx->a.pos2);
         std::swap(ctx->a.vel, ctx->a.vel2);
     } else {
+        refresh_velt(ctx);
         launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, false);
     }
     ctx->primed = fused(ctx);
+    ctx->velt_stale = fused(ctx);
     ctx->stepped = true;
     hipGraphExec_t g = ev ? nullptr : step_graph(ctx);
     if (g) HIPCHK(ctx, hipGraphLaunch(g, st));
@@ -380,7 +389,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / BOXG);      // box groups
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     ALLOC(a.slot, n > nb ? n : nb);
-    ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad);
+    ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad); ALLOC(a.bnear, pad);
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
@@ -427,6 +436,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.dirty, a.flags, n_boundary);
     launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild);
     launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary, bvel_in, a.bvel);
+    launch_boundary_near(st, ctx->c, a);
     if (psi_given) {
         // psi was computed on the full wall set (a slab sees only its part of the walls): scatter it to bin order
         float *psi_in = reinterpret_cast<float *>(bkey);      // bkey is dead after the reorder
@@ -519,6 +529,7 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
             hipGraphExec_t g = multi_graph(ctx);
             if (g) {
                 HIPCHK(ctx, hipGraphLaunch(g, ctx->stream));
+                ctx->velt_stale = true;
                 s += MULTI_STEPS;
                 continue;
             }
@@ -541,6 +552,7 @@ int sph_read_particles(sph_ctx *ctx, sph_particle *out) {
     if (!ctx || !ctx->stream || (!out && ctx->n)) return SPH_E_ARG;
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_read");
     (void)hipSetDevice(ctx->device);
+    refresh_velt(ctx);
     launch_unsort_particles(ctx->stream, ctx->c, ctx->a, ctx->n, ctx->d_aos);
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_aos, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -571,6 +583,7 @@ int sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_MAXRHO, 0, 2 * sizeof(uint32_t), ctx->stream));
+    refresh_velt(ctx);
     launch_stats(ctx->stream, ctx->a, ctx->n);
     uint32_t h[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags + FLAG_MAXRHO, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -634,7 +647,11 @@ size_t sph_device_bytes(const sph_ctx *ctx) { return ctx ? ctx->bytes : 0; }
 int sph_set_variant(sph_ctx *ctx, int variant) {
     if (!ctx || variant < 0 || variant > 1) return SPH_E_ARG;
     if (variant != ctx->variant) {
-        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stream) {
+            (void)hipSetDevice(ctx->device);
+            refresh_velt(ctx);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
         drop_graph(ctx);
         ctx->variant = variant;      // both variants work from the same sorted state
         ctx->primed = false;         // a look-ahead kick/drift of the list kernels is dropped, the current state kept
@@ -667,6 +684,7 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     // du_dt, dv_dt stay with their particles (reference: index-aligned arrays, :616): out to original order before
     // the arrays are rewritten, back in through the new sort order afterwards
     launch_unsort_accel(st, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
+    ctx->velt_stale = false;      // velt is rewritten below
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyHostToDevice, st));
     launch_upload_state(st, ctx->a, ctx->n, ctx->d_aos);
     ctx->primed = false;
@@ -684,6 +702,7 @@ int sph_upload_accel(sph_ctx *ctx, const float *du_dt, const float *dv_dt) {
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "stage entry points are single-GPU only");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
+    refresh_velt(ctx);            // with the accelerations of the last step, before they are replaced
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_du, du_dt, (size_t)ctx->n * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_dv, dv_dt, (size_t)ctx->n * sizeof(float), hipMemcpyHostToDevice, st));
     launch_gather_accel(st, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
@@ -714,6 +733,7 @@ int sph_eval_pressure(sph_ctx *ctx) {
 int sph_eval_accel(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
+    refresh_velt(ctx);            // with the accelerations of the last step, before they are replaced
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, FORCE_EVAL, ctx->variant);
     ctx->primed = false;         // the next step kicks with THIS du_dt (:616), not with a look-ahead made before it
@@ -792,6 +812,7 @@ int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
         std::swap(ctx->a.pos, ctx->a.pos2);
         std::swap(ctx->a.vel, ctx->a.vel2);
     } else {
+        refresh_velt(ctx);
         launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, true);
     }
     ctx->primed = fused(ctx);
@@ -836,6 +857,7 @@ int sph_slab_step_end(sph_ctx *ctx) {
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, ctx->slab_overlapped ? DENS_REST : DENS_ALL);
     launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
+    ctx->velt_stale = fused(ctx);
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_overlapped = false;
     ctx->slab_phase = 0;
@@ -925,6 +947,7 @@ int sph_slab_read(sph_ctx *ctx, sph_particle *out, uint32_t *ids, float *du_dt, 
     if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_read mid-step");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
+    refresh_velt(ctx);
     launch_export_owned(st, ctx->c, ctx->a, ctx->cap, ctx->d_aos, ctx->d_ids, ctx->d_du, ctx->d_dv);
     uint32_t hdn[4] = {0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(hdn, ctx->a.dn, sizeof hdn, hipMemcpyDeviceToHost, st));

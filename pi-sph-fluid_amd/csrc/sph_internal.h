@@ -82,6 +82,7 @@ struct Arrays {
     float *bpsi;
     uint32_t *bid;
     uint32_t *bcell_start; // n_cells + 1
+    unsigned char *bnear;  // per cell: a wall particle lies in the 3x3 cells around it (0 -> a fluid particle there skips the wall walk)
     // misc
     float2 *grav;       // gravity vector read by the force kernel
     uint32_t *flags;    // see FLAG_*
@@ -181,6 +182,8 @@ void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32
                              const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb, const float2 *bvel_in,
                              float2 *bvel);
 void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb);
+// per-cell flag "walls within reach" from the wall bins (init; again whenever the walls are re-binned)
+void launch_boundary_near(hipStream_t st, const Consts &c, const Arrays &a);
 void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *psi_in_original_order, int nb);
 // read-back helpers
 void launch_unsort_particles(hipStream_t st, const Consts &c, const Arrays &a, int n, sph_particle *out_dev);
@@ -190,6 +193,8 @@ void launch_unsort_boundary(hipStream_t st, const Consts &c, const Arrays &a, in
 void launch_upload_state(hipStream_t st, const Arrays &a, int n, const sph_particle *in_dev);
 void launch_gather_rho_p(hipStream_t st, const Consts &c, const Arrays &a, int n, const sph_particle *in_dev);
 void launch_stats(hipStream_t st, const Arrays &a, int n);
+// velt := vel + dt/2 acc (the velocity between steps, which the fused force pass does not store)
+void launch_refresh_velt(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 void launch_metaballs(hipStream_t st, const Consts &c, const Arrays &a, float width, float height,
                       unsigned char *page_bytes_dev /* 1024 bytes, SSD1306 page format */);
 

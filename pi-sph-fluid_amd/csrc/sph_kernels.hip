@@ -898,6 +898,22 @@ __global__ __launch_bounds__(BLK) void k_boundary_psi(Consts c, const float2 *__
     bpsi[i] = c.rho0 / (c.nf * s);      // psi = rho_0 / sum W   :259
 }
 
+// walls are few and static: most fluid particles have none within reach, and finding that out from the bins costs six
+// dependent loads per particle and pass.  One byte per cell answers it: is there a wall particle in the 3x3 cells around?
+__global__ __launch_bounds__(BLK) void k_boundary_near(Consts c, const uint32_t *__restrict__ bcs, unsigned char *__restrict__ bnear) {
+    const int cell = blockIdx.x * BLK + threadIdx.x;
+    if (cell >= c.n_cells) return;
+    int row, col;
+    cell_of_key(c, (uint32_t)cell, row, col);
+    const int r0 = max(row - 1, 0), r1 = min(row + 1, c.rows - 1);
+    uint32_t cnt = 0u;
+    for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) cnt += bcs[cc * c.rows + r1 + 1] - bcs[cc * c.rows + r0];
+    bnear[cell] = cnt ? 1 : 0;
+}
+void launch_boundary_near(hipStream_t st, const Consts &c, const Arrays &a) {
+    hipLaunchKernelGGL(k_boundary_near, dim3((c.n_cells + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.bcell_start, a.bnear);
+}
+
 __global__ __launch_bounds__(BLK) void k_boundary_gather_psi(const float *__restrict__ psi_in, const uint32_t *__restrict__ bid,
                                                              float *__restrict__ bpsi, int nb) {
     int i = blockIdx.x * BLK + threadIdx.x;
@@ -1011,6 +1027,20 @@ void launch_gather_rho_p(hipStream_t st, const Consts &c, const Arrays &a, int n
     (void)c;
     if (n <= 0) return;
     hipLaunchKernelGGL(k_gather_rho_p, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, in_dev, a.id, a.rp, a.prs, n);
+}
+
+// the velocity between steps (after the second half kick, :638-639) from the half-kicked velocity and the acceleration
+// of the last force pass: what the fused force pass would have stored, same fma
+__global__ __launch_bounds__(BLK) void k_refresh_velt(Consts c, const float2 *__restrict__ vel, const float2 *__restrict__ acc,
+                                                      float2 *__restrict__ velt, const uint32_t *__restrict__ dn) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= (int)dn[0]) return;
+    const float2 v = vel[i], a = acc[i];
+    velt[i] = make_float2(fmaf(c.half_dt, a.x, v.x), fmaf(c.half_dt, a.y, v.y));
+}
+void launch_refresh_velt(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+    if (cap <= 0) return;
+    hipLaunchKernelGGL(k_refresh_velt, dim3((cap + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.vel, a.acc, a.velt, a.dn);
 }
 
 // ------------------------------------------------------------------------------------------

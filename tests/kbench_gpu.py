@@ -25,7 +25,7 @@ for abl in (("0", "1", "2", "3", "0") if sph.LIB_HIP == ablate_lib else ("0",)):
     os.environ["SPH_ABLATE_DENS"] = abl
     print("density SPH_ABLATE_DENS=%s : %.2f us" % (abl, ctx.time_kernel("density_eos", 50) * 1e3))
 os.environ.pop("SPH_ABLATE_DENS", None)
-for abl in (("0", "1", "2", "3", "4", "6", "7", "0") if sph.LIB_HIP == ablate_lib else ("0",)):
+for abl in (("0", "1", "2", "4", "7", "8", "15", "16", "31", "32", "63", "0") if sph.LIB_HIP == ablate_lib else ("0",)):
     os.environ["SPH_ABLATE"] = abl
     print("force SPH_ABLATE=%s : %.2f us" % (abl, ctx.time_kernel("force_kick", 50) * 1e3))
 os.environ.pop("SPH_ABLATE", None)
