@@ -121,6 +121,12 @@ int  sph_read_particles(sph_ctx *ctx, sph_particle *out);
 int  sph_read_accel(sph_ctx *ctx, float *du_dt, float *dv_dt);
 /* boundary particles, original order, psi in .m (:259) */
 int  sph_read_boundary(sph_ctx *ctx, sph_particle *out);
+/* Walls that move (README.md:175-176 lists "boundary velocity" as not implemented; the hook is the wall particle's
+ * stored u, v in the fluid-boundary viscosity term, :357).  Overwrites x, y, u, v of every wall particle (original
+ * order, n_boundary of them) and re-bins the walls; psi is kept (:259: rigid motion does not change a wall particle's own
+ * wall neighbourhood).  Call between steps; the next step rebuilds the fluid's neighbour structure against the new bins.
+ * The walls must stay inside the domain box. */
+int  sph_update_boundary(sph_ctx *ctx, const sph_particle *boundary);
 /* the statistics of :657-671 as device reductions: max rho and max sqrt(u^2+v^2) over fluid */
 int  sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed);
 

@@ -31,6 +31,14 @@ long sph_scene_default_fluid(const sph_params *prm, sph_particle *out, long cap)
  * accumulate == 0 uses x = x_min + i*R (large boxes). */
 long sph_scene_walls(const sph_params *prm, int accumulate, sph_particle *out, long cap);
 
+/* Multi-layer walls (README.md:171-181 lists them as not implemented; Akinci's psi handles any wall sampling, :242-261):
+ * `layers` nested rectangular frames of wall particles with spacing R, the innermost on the rectangle
+ * [wx0,wx1] x [wy0,wy1], each further one R further out.  The frames must lie inside the domain box of prm (the
+ * neighbour grid), so the caller makes the box at least layers*R larger than the inner rectangle on every side.
+ * Corners are sampled once; the single-layer case differs from sph_scene_walls only in covering all four corners. */
+long sph_scene_walls_layers(const sph_params *prm, float wx0, float wx1, float wy0, float wy1, int layers,
+                            sph_particle *out, long cap);
+
 /* Disc of lattice points (x = i*R, y = j*R, i outer / j inner) with distance < radius from
  * (cx,cy): the "drop on dry surface" scene scaled up (cfg1). */
 long sph_scene_disc(const sph_params *prm, float cx, float cy, float radius, sph_particle *out, long cap);
@@ -42,6 +50,18 @@ long sph_scene_block(const sph_params *prm, float x0, float y0, long nx, long ny
  * (particle k of the range is particle i_begin*ny + k of the block): a slab host generates only what it holds. */
 long sph_scene_block_range(const sph_params *prm, float x0, float y0, long nx, long ny, long i_begin, long i_end,
                            sph_particle *out, long cap);
+
+/* ---- x-slab decomposition, host side (the reference has no distributed path) ---- */
+/* columns of the device grid (cell = 2H + skin 2H) and the column of a position, in the device's own f32 arithmetic */
+int  sph_slab_grid_columns(const sph_params *prm);
+int  sph_slab_column_of(const sph_params *prm, float x);
+/* cuts[0..world]: rank r owns cell columns [cuts[r], cuts[r+1]) of the lattice block (x0, nx, ny): contiguous ranges
+ * with ~equal particle counts (quantiles of the per-column histogram), every range at least 4 columns, the first
+ * beginning at column 0 and the last ending at the box edge (a dam-break front never leaves the decomposition). */
+int  sph_slab_partition_block(const sph_params *prm, float x0, long nx, long ny, int world, int *cuts);
+/* lattice columns [i_begin, i_end) of the block that lie in cell columns [col_begin - 2, col_end + 2): what the rank
+ * owning [col_begin, col_end) generates (sph_scene_block_range); global id of its k-th particle = i_begin * ny + k */
+int  sph_slab_block_columns(const sph_params *prm, float x0, long nx, int col_begin, int col_end, long *i_begin, long *i_end);
 
 /* ---- gravity source: get_gravity / get_gravity_routine (:431-464) ---- */
 typedef enum sph_gravity_kind {

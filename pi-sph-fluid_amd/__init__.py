@@ -36,7 +36,7 @@ STEP_ALGO_BYTES = 152.0
 ABI_SYMBOLS = [
     "sph_params_default", "sph_abi_version", "sph_error_string", "sph_device_count",
     "sph_create", "sph_destroy", "sph_last_error", "sph_step", "sph_sync",
-    "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_stats",
+    "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
     "sph_device_cell", "sph_rebuild_stats", "sph_check_stats",
     "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
@@ -48,8 +48,9 @@ ABI_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",
-    "sph_scene_block_range",
+    "sph_scene_block_range", "sph_scene_walls_layers",
     "sph_gravity_init", "sph_gravity_sample",
+    "sph_slab_grid_columns", "sph_slab_column_of", "sph_slab_partition_block", "sph_slab_block_columns",
 ]
 
 
@@ -120,6 +121,7 @@ def hip_lib():
         L.sph_read_particles.argtypes = [vp, vp]
         L.sph_read_accel.argtypes = [vp, vp, vp]
         L.sph_read_boundary.argtypes = [vp, vp]
+        L.sph_update_boundary.argtypes = [vp, vp]
         L.sph_stats.argtypes = [vp, C.POINTER(cf), C.POINTER(cf)]
         L.sph_n_fluid.argtypes = [vp]
         L.sph_n_boundary.argtypes = [vp]
@@ -178,8 +180,14 @@ def host_lib():
         L.sph_scene_disc.restype = cl
         L.sph_scene_block.argtypes = [C.POINTER(Params), cf, cf, cl, cl, vp, cl]
         L.sph_scene_block.restype = cl
+        L.sph_scene_walls_layers.argtypes = [C.POINTER(Params), cf, cf, cf, cf, C.c_int, vp, cl]
+        L.sph_scene_walls_layers.restype = cl
         L.sph_scene_block_range.argtypes = [C.POINTER(Params), cf, cf, cl, cl, cl, cl, vp, cl]
         L.sph_scene_block_range.restype = cl
+        L.sph_slab_grid_columns.argtypes = [C.POINTER(Params)]
+        L.sph_slab_column_of.argtypes = [C.POINTER(Params), cf]
+        L.sph_slab_partition_block.argtypes = [C.POINTER(Params), cf, cl, cl, C.c_int, C.POINTER(C.c_int)]
+        L.sph_slab_block_columns.argtypes = [C.POINTER(Params), cf, cl, C.c_int, C.c_int, C.POINTER(cl), C.POINTER(cl)]
         L.sph_gravity_init.argtypes = [C.POINTER(Gravity), C.c_int, cf]
         L.sph_gravity_init.restype = None
         L.sph_gravity_sample.argtypes = [C.POINTER(Gravity), cf, C.POINTER(cf), C.POINTER(cf)]
@@ -221,6 +229,11 @@ def scene_default(prm=None):
 def scene_walls(prm, accumulate=False):
     """the wall generator of :523-540 for the box of prm (single layer, spacing R)."""
     return _two_call(host_lib().sph_scene_walls, C.byref(prm), 1 if accumulate else 0)
+
+
+def scene_walls_layers(prm, wall_box, layers):
+    """`layers` nested frames of wall particles, the innermost on wall_box = (x0, x1, y0, y1), all inside prm's box."""
+    return _two_call(host_lib().sph_scene_walls_layers, C.byref(prm), *[float(v) for v in wall_box], int(layers))
 
 
 def scene_disc(box, cx, cy, radius):
@@ -346,6 +359,12 @@ class Context:
         out = np.zeros(self.nb, PARTICLE)
         self._chk(self.L.sph_read_boundary(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def update_boundary(self, boundary):
+        """move the walls: x, y, u, v of every wall particle (original order); psi is kept."""
+        boundary = np.ascontiguousarray(boundary, PARTICLE)
+        assert len(boundary) == self.nb
+        self._chk(self.L.sph_update_boundary(self.h, boundary.ctypes.data_as(C.c_void_p)))
 
     def stats(self):
         a, b = C.c_float(), C.c_float()

@@ -37,6 +37,9 @@ struct sph_ctx {
     sph_particle *d_aos = nullptr;    // n  : read-back / upload staging, original order
     sph_particle *d_baos = nullptr;   // nb
     float *d_du = nullptr, *d_dv = nullptr;
+    float2 *d_bpos_in = nullptr, *d_bvel_in = nullptr;   // nb : wall particles as given (original order), staging of the wall bins
+    uint32_t *d_bkey = nullptr;       // nb : their cells
+    float *d_bpsi0 = nullptr;         // nb : pseudo-mass in original order (kept across sph_update_boundary)
     unsigned char *d_bits = nullptr;  // metaball frame, 1024 bytes of SSD1306 page format
     std::vector<void *> allocs;
     size_t bytes = 0;
@@ -395,9 +398,9 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 1024);
     ALLOC(ctx->d_ids, n);
-    float2 *bpos_in = nullptr, *bvel_in = nullptr;
-    uint32_t *bkey = nullptr;
-    ALLOC(bpos_in, nb); ALLOC(bvel_in, nb); ALLOC(bkey, nb);
+    float2 *&bpos_in = ctx->d_bpos_in, *&bvel_in = ctx->d_bvel_in;
+    uint32_t *&bkey = ctx->d_bkey;
+    ALLOC(bpos_in, nb); ALLOC(bvel_in, nb); ALLOC(bkey, nb); ALLOC(ctx->d_bpsi0, nb);
     a.send[0] = a.send[1] = a.recv[0] = a.recv[1] = nullptr;
     if (slab) {
         ctx->halo_bytes = sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * slab->halo_cap);
@@ -439,11 +442,11 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     launch_boundary_near(st, ctx->c, a);
     if (psi_given) {
         // psi was computed on the full wall set (a slab sees only its part of the walls): scatter it to bin order
-        float *psi_in = reinterpret_cast<float *>(bkey);      // bkey is dead after the reorder
-        HIPCHK(ctx, hipMemcpyAsync(psi_in, hpsi.data(), nb * sizeof(float), hipMemcpyHostToDevice, st));
-        launch_boundary_gather_psi(st, a, psi_in, n_boundary);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_bpsi0, hpsi.data(), nb * sizeof(float), hipMemcpyHostToDevice, st));
+        launch_boundary_gather_psi(st, a, ctx->d_bpsi0, n_boundary);
     } else {
         launch_boundary_psi(st, ctx->c, a, n_boundary);
+        launch_boundary_unsort_psi(st, a, ctx->d_bpsi0, n_boundary);      // original order, for sph_update_boundary
     }
 
     // fluid: upload, bin, then rho, p, a at t = 0 (:604-607)
@@ -577,6 +580,36 @@ int sph_read_boundary(sph_ctx *ctx, sph_particle *out) {
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_baos, (size_t)ctx->nb * sizeof(sph_particle), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SPH_OK;
+}
+
+int sph_update_boundary(sph_ctx *ctx, const sph_particle *boundary) {
+    if (!ctx || !ctx->stream || (!boundary && ctx->nb)) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_update_boundary is single-GPU only");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    Arrays &a = ctx->a;
+    const size_t nb = (size_t)ctx->nb;
+    std::vector<float2> hb(nb ? nb : 1), hbv(nb ? nb : 1);
+    for (size_t i = 0; i < nb; i++) {
+        hb[i] = make_float2(boundary[i].x, boundary[i].y);
+        hbv[i] = make_float2(boundary[i].u, boundary[i].v);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_bpos_in, hb.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_bvel_in, hbv.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
+    // re-bin the walls (the histogram array is zero between sorts; the scan is gated by the rebuild word), pseudo-mass
+    // follows its particle (rigid motion leaves the wall's own neighbourhood, hence psi :259, unchanged)
+    launch_set_rebuild(st, a, true);
+    launch_boundary_key(st, ctx->c, ctx->d_bpos_in, ctx->d_bkey, a.slot, a.count, a.dirty, a.flags, ctx->nb);
+    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild);
+    launch_boundary_reorder(st, ctx->d_bpos_in, ctx->d_bkey, a.slot, a.bcell_start, a.bpos, a.bid, ctx->nb, ctx->d_bvel_in, a.bvel);
+    launch_boundary_gather_psi(st, a, ctx->d_bpsi0, ctx->nb);
+    launch_boundary_near(st, ctx->c, a);
+    // the rebuild word stays raised: the tile records count the wall particles in reach of each tile, so the next step
+    // rebuilds the fluid's neighbour structure against the new wall bins (this also keeps a request the last force
+    // pass may have left for that step)
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));      // hb / hbv are free again
+    return check_flags(ctx);
 }
 
 int sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed) {

@@ -185,6 +185,7 @@ void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int n
 // per-cell flag "walls within reach" from the wall bins (init; again whenever the walls are re-binned)
 void launch_boundary_near(hipStream_t st, const Consts &c, const Arrays &a);
 void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *psi_in_original_order, int nb);
+void launch_boundary_unsort_psi(hipStream_t st, const Arrays &a, float *psi_out_original_order, int nb);
 // read-back helpers
 void launch_unsort_particles(hipStream_t st, const Consts &c, const Arrays &a, int n, sph_particle *out_dev);
 void launch_unsort_accel(hipStream_t st, const Arrays &a, int n, float *du, float *dv);

@@ -920,6 +920,16 @@ __global__ __launch_bounds__(BLK) void k_boundary_gather_psi(const float *__rest
     if (i >= nb) return;
     bpsi[i] = psi_in[bid[i]];
 }
+__global__ __launch_bounds__(BLK) void k_boundary_unsort_psi(const float *__restrict__ bpsi, const uint32_t *__restrict__ bid,
+                                                             float *__restrict__ psi_out, int nb) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= nb) return;
+    psi_out[bid[i]] = bpsi[i];
+}
+void launch_boundary_unsort_psi(hipStream_t st, const Arrays &a, float *psi_out_original_order, int nb) {
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_boundary_unsort_psi, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, a.bpsi, a.bid, psi_out_original_order, nb);
+}
 void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *psi_in, int nb) {
     if (nb <= 0) return;
     hipLaunchKernelGGL(k_boundary_gather_psi, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, psi_in, a.bid, a.bpsi, nb);

@@ -8,7 +8,10 @@
  * text (--show) and gravity comes from sph_gravity (constant, scripted tilt, or the sysfs reader).
  *
  *   desktop_sph_fluid [--scene cfg0|cfg1|cfg2|cfg3|cfg4] [--steps N] [--realtime] [--tilt]
- *                     [--mpu6050 DIR] [--show] [--batch K] [--device D]
+ *                     [--tilt-amp DEG] [--tilt-period S] [--tilt-hold S] [--mpu6050 DIR] [--show] [--batch K]
+ *                     [--device D] [--skin F] [--dump-frame FILE] [--dump-state FILE]
+ * --dump-frame: the 1024-byte SSD1306 page-format frame of the final state (what ssd1306_drawBufferFast would be
+ * handed, :469); --dump-state: the final fluid[] array (struct particle, 28 bytes each, :26-31).
  */
 #include <math.h>
 #include <stdio.h>
@@ -47,7 +50,8 @@ int main(int argc, char **argv) {
     const char *scene = "cfg0";
     long max_steps = 0;
     int realtime = 0, show = 0, batch = 1, device = 0, gkind = SPH_GRAVITY_CONSTANT;
-    const char *mpu_dir = NULL;
+    const char *mpu_dir = NULL, *dump_frame = NULL, *dump_state = NULL;
+    float tilt_amp = -1, tilt_period = -1, tilt_hold = -1, skin = -1;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) max_steps = atol(argv[++i]);
@@ -56,6 +60,12 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--realtime")) realtime = 1;        /* the REALTIME define, :10 */
         else if (!strcmp(argv[i], "--show")) show = 1;
         else if (!strcmp(argv[i], "--tilt")) gkind = SPH_GRAVITY_TILT;
+        else if (!strcmp(argv[i], "--tilt-amp") && i + 1 < argc) tilt_amp = (float)atof(argv[++i]);
+        else if (!strcmp(argv[i], "--tilt-period") && i + 1 < argc) tilt_period = (float)atof(argv[++i]);
+        else if (!strcmp(argv[i], "--tilt-hold") && i + 1 < argc) tilt_hold = (float)atof(argv[++i]);
+        else if (!strcmp(argv[i], "--skin") && i + 1 < argc) skin = (float)atof(argv[++i]);
+        else if (!strcmp(argv[i], "--dump-frame") && i + 1 < argc) dump_frame = argv[++i];
+        else if (!strcmp(argv[i], "--dump-state") && i + 1 < argc) dump_state = argv[++i];
         else if (!strcmp(argv[i], "--mpu6050") && i + 1 < argc) { gkind = SPH_GRAVITY_MPU6050; mpu_dir = argv[++i]; }
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -64,6 +74,7 @@ int main(int argc, char **argv) {
     /* ---- scene (:484-540) ---- */
     sph_params prm;
     sph_params_default(&prm);
+    if (skin >= 0) prm.skin = skin;
     long n_fluid = 0, n_boundary = 0;
     sph_particle *fluid = NULL, *boundary = NULL;
     int accumulate = 0;
@@ -96,6 +107,9 @@ int main(int argc, char **argv) {
     sph_gravity grav;
     sph_gravity_init(&grav, gkind, prm.g);
     if (mpu_dir) { strncpy(grav.sysfs_dir, mpu_dir, sizeof grav.sysfs_dir - 1); }
+    if (tilt_amp >= 0) grav.amp_deg = tilt_amp;
+    if (tilt_period > 0) grav.period_s = tilt_period;
+    if (tilt_hold >= 0) grav.hold_s = tilt_hold;
     float gx, gy;
     int rc = sph_gravity_sample(&grav, 0.0f, &gx, &gy);
     if (rc) return die(NULL, "sph_gravity_sample", rc);
@@ -162,6 +176,21 @@ int main(int argc, char **argv) {
     float max_rho, max_speed;
     sph_stats(ctx, &max_rho, &max_speed);
     printf("done: %ld steps, sim time %.3f s, max rho %.2f, max speed %.2f m/s\n", steps, t, max_rho, max_speed);
+    if (dump_frame) {                                                              /* the frame of the final state */
+        rc = sph_render_metaballs(ctx, draw_buffer);
+        if (rc) return die(ctx, "sph_render_metaballs", rc);
+        FILE *fh = fopen(dump_frame, "wb");
+        if (!fh || fwrite(draw_buffer, 1, 1024, fh) != 1024) { fprintf(stderr, "cannot write %s\n", dump_frame); return 1; }
+        fclose(fh);
+        if (show) show_frame(draw_buffer);
+    }
+    if (dump_state) {                                                              /* fluid[] as main() would hold it */
+        rc = sph_read_particles(ctx, fluid);
+        if (rc) return die(ctx, "sph_read_particles", rc);
+        FILE *fh = fopen(dump_state, "wb");
+        if (!fh || fwrite(fluid, sizeof(sph_particle), (size_t)n_fluid, fh) != (size_t)n_fluid) { fprintf(stderr, "cannot write %s\n", dump_state); return 1; }
+        fclose(fh);
+    }
     sph_destroy(ctx);
     free(draw_buffer); free(fluid); free(boundary);
     return 0;

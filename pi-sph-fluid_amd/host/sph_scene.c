@@ -71,6 +71,36 @@ long sph_scene_walls(const sph_params *p, int accumulate, sph_particle *out, lon
     return n;
 }
 
+long sph_scene_walls_layers(const sph_params *p, float wx0, float wx1, float wy0, float wy1, int layers,
+                            sph_particle *out, long cap) {
+    if (!p || layers < 1 || !(wx1 > wx0) || !(wy1 > wy0)) return SPH_E_ARG;
+    const float r = p->r;
+    if (wx0 - (float)(layers - 1) * r < p->x_min || wx1 + (float)(layers - 1) * r > p->x_max ||
+        wy0 - (float)(layers - 1) * r < p->y_min || wy1 + (float)(layers - 1) * r > p->y_max)
+        return SPH_E_ARG;                                   /* frames must stay inside the neighbour grid */
+    long n = 0;
+    for (int l = 0; l < layers; l++) {
+        const float x0 = wx0 - (float)l * r, x1 = wx1 + (float)l * r, y0 = wy0 - (float)l * r, y1 = wy1 + (float)l * r;
+        const long nx = (long)floorf((x1 - x0) / r + 0.5f), ny = (long)floorf((y1 - y0) / r + 0.5f);
+        /* bottom and top edges including both corners, then the side edges without them */
+        for (long i = 0; i <= nx; i++) {
+            const float x = i == nx ? x1 : x0 + (float)i * r;
+            if (out && n + 2 > cap) return SPH_E_ARG;
+            put(out, n, x, y0, 0, p->rho0);
+            put(out, n + 1, x, y1, 0, p->rho0);
+            n += 2;
+        }
+        for (long j = 1; j < ny; j++) {
+            const float y = y0 + (float)j * r;
+            if (out && n + 2 > cap) return SPH_E_ARG;
+            put(out, n, x0, y, 0, p->rho0);
+            put(out, n + 1, x1, y, 0, p->rho0);
+            n += 2;
+        }
+    }
+    return n;
+}
+
 long sph_scene_disc(const sph_params *p, float cx, float cy, float radius, sph_particle *out, long cap) {
     if (!p || !(radius > 0)) return SPH_E_ARG;
     const float m = p->rho0 * p->vol;

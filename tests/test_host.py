@@ -145,3 +145,21 @@ def test_skin_is_a_per_context_parameter(sph):
     with pytest.raises(sph.SphError) as e:
         sph.Context(prm, f, b)
     assert e.value.code == sph.SPH_E_ARG               # rejected before any device is touched
+
+
+def test_multi_layer_wall_generator(sph):
+    prm = sph.default_params((0.0, 6.0, 0.0, 4.0))
+    inner = (0.5, 5.5, 0.5, 3.5)
+    one, three = sph.scene_walls_layers(prm, inner, 1), sph.scene_walls_layers(prm, inner, 3)
+    r = np.float32(prm.r)
+    for w, layers in ((one, 1), (three, 3)):
+        xy = np.stack([w["x"], w["y"]], 1)
+        assert len(np.unique(xy, axis=0)) == len(w)                      # corners sampled once
+        assert abs(w["x"].min() - (0.5 - (layers - 1) * r)) < 1e-6 and abs(w["y"].max() - (3.5 + (layers - 1) * r)) < 1e-6
+        on_frame = (np.isclose(w["x"], w["x"].min()) | np.isclose(w["x"], w["x"].max()) |
+                    np.isclose(w["y"], w["y"].min()) | np.isclose(w["y"], w["y"].max()))
+        assert on_frame.sum() >= len(w) // layers - 8
+        assert np.all(w["m"] == 0) and np.all(w["rho"] == prm.rho0)
+    assert len(three) > 3 * len(one)                                     # outer frames are longer
+    L = sph.host_lib()
+    assert L.sph_scene_walls_layers(C.byref(prm), 0.05, 5.5, 0.5, 3.5, 2, None, 0) == sph.SPH_E_ARG      # outer frame leaves the box
