@@ -63,7 +63,7 @@ def test_c_host_one_rank_equals_sph_step(sph):
                        capture_output=True, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     out = r.stdout.decode().splitlines()
-    rec = json.loads(out[0])
+    rec = json.loads([ln for ln in out if ln.startswith("{")][0])      # (RCCL prints a version banner on stdout first)
     assert rec["n_gpus"] == 1 and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True
     assert rec["ticks_per_s"] > 0 and 0 < rec["neighbour_rebuilds"] < 200
     chk = [ln for ln in out if ln.startswith("check:")]
@@ -75,7 +75,7 @@ def test_c_host_tilt_run_and_rank_count_guard(sph):
     r = subprocess.run([HOST, "--ranks", "1", "--scene", "dam", "--steps", "60", "--warmup", "20", "--tilt"],
                        capture_output=True, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    rec = json.loads(r.stdout.decode().splitlines()[0])
+    rec = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert rec["n_fluid"] == 2000000 and rec["particles_conserved"] is True and "tilt" in rec["workload"]
     ndev = sph.hip_lib().sph_device_count()
     r = subprocess.run([HOST, "--ranks", str(ndev + 1), "--block", "400", "100", "60", "20", "--steps", "2", "--warmup", "1"],
