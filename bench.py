@@ -58,24 +58,41 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
-def run_single(sph, name, steps, warmup, profile_steps=20, skin=None):
-    """K timed steps of one scene on device 0; returns a result dict."""
+def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False):
+    """K timed steps of one scene on device 0; returns a result dict.  tilt: gravity from the scripted tilt trace
+    (sph_gravity: 15 deg, 8 s period, re-sampled every 0.1 s of simulated time like the reference's 10 Hz poll,
+    pi_sph_fluid.c:455-461), one sph_step call per step as the reference re-reads g every step (:632)."""
     prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
     if skin is not None:
         prm.skin = skin
     n = len(f)
+    grav = sph.GravitySource(sph.GRAVITY_TILT, 9.81) if tilt else None
+    dt_sim = float(np.float32(prm.dt))
+    sim = [0]
+
+    def advance(k):
+        if grav is None:
+            ctx.step(k, 0.0, -9.81)
+            return
+        for _ in range(k):
+            gx, gy = grav.sample(sim[0] * dt_sim)
+            ctx.step(1, gx, gy)
+            sim[0] += 1
+
     t0 = time.time()
-    ctx = sph.Context(prm, f, b, 0.0, -9.81, device=0)
+    g0 = grav.sample(0.0) if grav else (0.0, -9.81)
+    ctx = sph.Context(prm, f, b, g0[0], g0[1], device=0)
     create_s = time.time() - t0
-    ctx.step(warmup, 0.0, -9.81)
+    del f
+    advance(warmup)
     ctx.sync()
     r0, _ = ctx.rebuild_stats()
     t0 = time.perf_counter()
-    ctx.step(steps, 0.0, -9.81)
+    advance(steps)
     ctx.sync()
     dt = time.perf_counter() - t0
     r1, _ = ctx.rebuild_stats()
-    kt = ctx.profile_steps(profile_steps, 0.0, -9.81)      # HIP events on the kernels' own stream
+    kt = ctx.profile_steps(profile_steps, *(grav.sample(sim[0] * dt_sim) if grav else (0.0, -9.81)))      # HIP events on the kernels' own stream
     ctx.sync()
     # the two heavy kernels are idempotent: time back-to-back launches on the live state (no per-launch
     # event overhead; this is the figure that must agree with rocprofv3's average kernel duration)
@@ -94,8 +111,17 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None):
     return res
 
 
+# SURVEY.md 8d, algorithmic bytes per particle and pass.  The 152 B step assumes the reference's structure: a rebuild of
+# the neighbour structure every step (:626).  Here a rebuild happens only in some steps, so the passes that actually
+# ran move fewer algorithmic bytes: P5 + P6 + the fused P1 (without its key) always, the sort passes per rebuild.
+ALGO_ALWAYS = 16.6 + 40.0 + 40.0
+ALGO_PER_REBUILD = 4.0 + 5.2 + 1.2 + 44.0
+FORCE_FUSED_NET = 40.0 + 40.0 - 24.0        # the fusion keeps x, y, u, v, ax, ay in registers: P1's 24 B of reads never happen
+
+
 def roofline(sph, res):
-    """HBM roofline of the dominant kernel: algorithmic bytes per launch / its mean launch duration."""
+    """HBM roofline of the dominant kernel: algorithmic bytes per launch / its mean launch duration (HIP events on the
+    kernels' own stream, back-to-back launches on the live state)."""
     kt = res["kernel_ms"]
     cand = {k: kt[k] for k in ("kick_drift", "density_eos", "force_kick")}
     dom = max(cand, key=cand.get)
@@ -103,6 +129,8 @@ def roofline(sph, res):
     achieved = algo / (kt[dom] * 1e-3) / 1e9
     step_bytes = sph.STEP_ALGO_BYTES * res["n_fluid"]
     step_gbs = step_bytes * res["steps_per_s"] / 1e9
+    exec_bytes = (ALGO_ALWAYS + ALGO_PER_REBUILD * res["timed_rebuilds_per_step"]) * res["n_fluid"]
+    exec_gbs = exec_bytes * res["steps_per_s"] / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):          # PMC passes are collected offline with rocprofv3 (see profiles/README.md)
@@ -110,31 +138,67 @@ def roofline(sph, res):
             traffic = json.load(open(tpath)).get(res["workload"], {}).get(dom)
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algo_bytes_per_launch": algo, "kernel_ms": round(kt[dom], 5),
-            "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
-            "step_algo_bytes": step_bytes}
+    out = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+           "algo_bytes_per_launch": algo, "kernel_ms": round(kt[dom], 5),
+           "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+           "step_algo_bytes": step_bytes,
+           # the same step priced on the passes that actually ran in the timed window (no credit for sort passes of
+           # steps that did not rebuild)
+           "step_executed_bytes": round(exec_bytes), "step_frac_executed": round(exec_gbs / HBM_PEAK_GBS, 4)}
+    if dom == "force_kick":
+        net = FORCE_FUSED_NET * res["n_fluid"]
+        out["frac_fused_net"] = round(net / (kt[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)      # 56 B: what the fused kernel must move
+    return out
 
 
-def cpu_baseline(sph, name, nsteps=8, warm=2):
-    """The oracle (CPU restatement of the reference, reference flags -Ofast -march=native -fopenmp) timed
-    on this host's cores on the same scene: the 'port' baseline (the reference itself cannot run
-    > 65 534 particles: unsigned short indices, pi_sph_fluid.c:78-79)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import orc
-    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liborc_fast.so"])   # -march=native of THIS host
-    O = orc.Oracle("fast")
-    prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
-    p = O.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
-    of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()
-    threads = os.cpu_count() or 1
-    O.psi(p, ob)
-    du, dv = O.eval(p, of, ob, 0.0, -9.81, threads=threads)
-    O.steps(p, of, ob, 0.0, -9.81, du, dv, warm, threads=threads)
+_CPU_LEG = r"""
+import importlib, json, os, sys, time
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import numpy as np
+import orc
+sph = importlib.import_module("pi-sph-fluid_amd")
+name, threads, nsteps, windows = {name!r}, {threads}, {nsteps}, {windows}
+O = orc.Oracle("fast")
+prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
+p = O.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
+of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()
+O.psi(p, ob)
+du, dv = O.eval(p, of, ob, 0.0, -9.81, threads=threads)
+O.steps(p, of, ob, 0.0, -9.81, du, dv, 2, threads=threads)
+rates = []
+for w in range(windows):
     t0 = time.perf_counter()
     O.steps(p, of, ob, 0.0, -9.81, du, dv, nsteps, threads=threads)
-    dt = time.perf_counter() - t0
+    rates.append(nsteps / (time.perf_counter() - t0))
+print(json.dumps({{"rates": rates, "n": len(f)}}))
+"""
+
+
+def physical_cores():
+    """one logical CPU per physical core among those this process may run on"""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, cores = set(), []
+    for cpu in allowed:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu).read().strip()
+        except OSError:
+            sib = str(cpu)
+        if sib not in seen:
+            seen.add(sib)
+            cores.append(cpu)
+    return cores, len(allowed)
+
+
+def cpu_baseline(sph, name, nsteps=20, windows=3):
+    """The oracle (CPU restatement of the reference, reference flags -Ofast -march=native -fopenmp) timed on this
+    host's cores on the same scene: the 'port' baseline (the reference itself cannot run > 65 534 particles: unsigned
+    short indices, pi_sph_fluid.c:78-79).  Two legs, each in a fresh process so that OpenMP reads its binding:
+    (a) 4 threads, the reference's shipped setting (:610); (b) one thread per physical core this process may use,
+    OMP_PROC_BIND=close OMP_PLACES=cores.  Median of `windows` windows of `nsteps` steps each; the better leg is the
+    baseline."""
+    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liborc_fast.so"])   # -march=native of THIS host
+    cores, logical = physical_cores()
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -143,10 +207,27 @@ def cpu_baseline(sph, name, nsteps=8, warm=2):
                 break
     except OSError:
         pass
-    return {"value": round(nsteps / dt * len(f) / 1e6, 3), "unit": "Mparticle-steps/s",
-            "timesteps_per_s": round(nsteps / dt, 4), "cores": threads, "kind": "port",
-            "sample": "%d steps (after %d warm-up) of the full %s scene, %d fluid particles, %d OpenMP threads, %s"
-                      % (nsteps, warm, name, len(f), threads, model)}
+    legs = []
+    for label, threads, extra in (("4 threads (reference setting :610)", min(4, len(cores)), {}),
+                                  ("all physical cores, bound", len(cores), {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"})):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), **extra)
+        code = _CPU_LEG.format(root=ROOT, name=name, threads=threads, nsteps=nsteps, windows=windows)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=900)
+        if r.returncode != 0:
+            log("cpu_baseline leg failed:", r.stderr.decode()[-500:])
+            continue
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        rate = float(np.median(d["rates"]))
+        n_fluid = d["n"]
+        legs.append({"label": label, "threads": threads, "timesteps_per_s": round(rate, 4),
+                     "value": round(rate * d["n"] / 1e6, 3), "windows": [round(x, 4) for x in d["rates"]]})
+        log("cpu_baseline:", legs[-1])
+    best = max(legs, key=lambda l: l["value"])
+    return {"value": best["value"], "unit": "Mparticle-steps/s", "timesteps_per_s": best["timesteps_per_s"],
+            "cores": best["threads"], "kind": "port", "legs": legs,
+            "sample": "median of %d windows of %d steps (after 2 warm-up) of the full %s scene, %d fluid particles; best of two "
+                      "legs (%s); host: %s, %d physical cores / %d logical CPUs available to this process"
+                      % (windows, nsteps, name, n_fluid, best["label"], model, len(cores), logical)}
 
 
 def launch_ranks(args):
@@ -261,6 +342,19 @@ def main():
                             "neighbour_rebuilds_per_step": round(r2["timed_rebuilds_per_step"], 4),
                             "max_speed": round(r2["max_speed"], 2),
                             "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r2["n_fluid"] * r2["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)})
+    if not args.no_also and args.workload == "cfg2":
+        # cfg4 as BASELINE.json states it, on ONE GPU: 32 000 000 particles (7.4 GB of device memory: the HBM-resident
+        # point, nothing fits the 256 MiB Infinity Cache) under the scripted tilt trace
+        r4 = run_single(sph, "cfg4", max(min(args.steps, 200), 1), min(args.warmup, 50), profile_steps=5, skin=args.skin, tilt=True)
+        log("also:", json.dumps(r4))
+        out["also"].append({"workload": "cfg4 on one GPU: %d fluid + %d boundary, box 2400.6 x 150 m, scripted tilt gravity"
+                                        % (r4["n_fluid"], r4["n_boundary"]),
+                            "value": round(r4["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
+                            "timesteps_per_s": round(r4["steps_per_s"], 2), "ms_per_step": round(r4["ms_per_step"], 5),
+                            "kernel_ms": {k: round(v, 5) for k, v in r4["kernel_ms"].items()},
+                            "neighbour_rebuilds_per_step": round(r4["timed_rebuilds_per_step"], 4),
+                            "device_mb": round(r4["device_mb"], 1),
+                            "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r4["n_fluid"] * r4["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)})
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sph, args.workload)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
