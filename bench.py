@@ -281,6 +281,7 @@ def main():
     ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "rccl"), choices=["rccl", "host"],
                     help="N > 1: halo transport. rccl = torch.distributed nccl backend (RCCL over xGMI), one GPU per "
                          "rank; host = host-staged gloo (rehearsal: all ranks may share one device)")
+    ap.add_argument("--lib", default=None, help="A/B measurements: load this build of libsph_hip.so instead of the in-tree one")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin as a fraction of 2H (default: the library's)")
     ap.add_argument("--slabs-on-one-gpu", action="store_true",
                     help="run the N = 1 workload through the slab path (one slab, no exchange): its overhead")
@@ -289,6 +290,8 @@ def main():
     sph = importlib.import_module("pi-sph-fluid_amd")
     if not (os.path.exists(sph.LIB_HIP) and os.path.exists(sph.LIB_HOST)):
         sph.build()      # before any rank starts
+    if args.lib:
+        sph.LIB_HIP = os.path.abspath(args.lib)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
