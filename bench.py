@@ -270,6 +270,53 @@ def launch_ranks(args):
     return 0
 
 
+def run_c_host(sph, args):
+    """N > 1 (default): the C multi-GPU host (pi-sph-fluid_amd/host/slab_sph_fluid.c: one process per GPU, halo
+    exchange and rebuild-word reduction over RCCL, no torch in the loop).  Started here as N ranks, or — under torchrun
+    — as the one rank this process stands for (the ncclUniqueId then travels through a file named after the job)."""
+    host = os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid")
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    scene = {"cfg2": "dam", "dam": "dam", "cfg3": "cfg3", "cfg4": "cfg4"}[args.workload]
+    cmd = [host, "--scene", scene, "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.workload == "cfg4":
+        cmd.append("--tilt")
+    if world:          # torchrun started the ranks: this process is one of them
+        rank = int(os.environ.get("RANK", "0"))
+        idfile = "/tmp/sph_bench_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        cmd += ["--ranks", str(world), "--rank", str(rank), "--id-file", idfile]
+    else:
+        rank, world = 0, args.gpus
+        cmd += ["--ranks", str(world)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or (rank == 0 and not lines):
+        log("bench.py: slab_sph_fluid exited with", r.returncode)
+        sys.exit(r.returncode or 1)
+    if rank != 0:
+        return
+    d = json.loads(lines[-1])
+    n_total, tps = d["n_fluid"], d["ticks_per_s"]
+    step_gbs = sph.STEP_ALGO_BYTES * n_total * tps / 1e9 / world
+    emit({
+        "metric": "SPH Mparticle-steps/sec (N_fluid x timesteps/sec / 1e6)",
+        "value": round(d["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s", "timesteps_per_s": round(tps, 2),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": d["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak" if scene == "dam" else "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s: %d fluid + %d boundary particles" % (d["workload"], n_total, d["n_boundary"]),
+                   "n_fluid": n_total, "n_boundary": d["n_boundary"],
+                   "parallelism": "%d x-slabs, one process per GPU, C host (slab_sph_fluid): 2-column halo + migration in one "
+                                  "ncclSend/ncclRecv pair per neighbour per step, 4-byte ncclAllReduce(max) of the rebuild word" % world},
+        "particles_conserved": d["particles_conserved"],
+        "neighbour_rebuilds_per_step": round(d["neighbour_rebuilds"] / max(args.steps + args.warmup, 1), 4),
+        "roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s per GPU (whole step, 152 B per particle-step)", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None},
+    })
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +330,8 @@ def main():
                          "rank; host = host-staged gloo (rehearsal: all ranks may share one device)")
     ap.add_argument("--lib", default=None, help="A/B measurements: load this build of libsph_hip.so instead of the in-tree one")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin as a fraction of 2H (default: the library's)")
+    ap.add_argument("--slab-host", default="c", choices=["c", "python"],
+                    help="N > 1: c = the C host over RCCL (slab_sph_fluid), python = torch.distributed (bench_slab.py)")
     ap.add_argument("--slabs-on-one-gpu", action="store_true",
                     help="run the N = 1 workload through the slab path (one slab, no exchange): its overhead")
     args = ap.parse_args()
@@ -293,6 +342,11 @@ def main():
     if args.lib:
         sph.LIB_HIP = os.path.abspath(args.lib)
 
+    slabbed = args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.slabs_on_one_gpu
+    if slabbed and args.slab_host == "c" and args.transport == "rccl":
+        quiet_stdout()
+        run_c_host(sph, args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     quiet_stdout()

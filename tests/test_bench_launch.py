@@ -14,7 +14,8 @@ import pytest
 
 from conftest import ROOT
 
-CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "6", "--warmup", "3"]
+CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--slab-host", "python",
+       "--steps", "6", "--warmup", "3"]
 
 
 def test_self_launch_fails_loudly_without_gpu(sph):
@@ -39,3 +40,35 @@ def test_self_launch_two_ranks_on_one_gpu(sph):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["particles_conserved"] is True
     assert out["config"]["n_fluid"] == 4000000 and out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_c_host_path_fails_loudly_without_gpu(sph):
+    """the default N > 1 path (the C host over RCCL) through bench.py: two ranks, no GPU -> non-zero, at once"""
+    if sph.hip_lib().sph_device_count() > 0:
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
+                       capture_output=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and b"no HIP device available" in r.stderr
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_c_host_path_one_slab(sph):
+    """bench.py's N > 1 leg with one rank: the C host over RCCL (ncclCommInitRank with one rank), JSON line of the contract"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--slabs-on-one-gpu", "--steps", "40",
+                        "--warmup", "10"], capture_output=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["particles_conserved"] is True and out["config"]["n_fluid"] == 2000000
+    assert out["unit"] == "Mparticle-steps/s" and out["value"] > 0 and "roofline" in out
+    # and under a torchrun-style environment (the driver's launch form): the rank comes from RANK / WORLD_SIZE
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29777")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--slabs-on-one-gpu", "--steps", "20",
+                        "--warmup", "5"], capture_output=True, timeout=600, env=env2, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["particles_conserved"] is True
