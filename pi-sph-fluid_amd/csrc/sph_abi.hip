@@ -162,7 +162,7 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     if (!ctx->slab) launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2: do neighbouring waves still move together?
     launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
     if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
     if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
@@ -259,7 +259,7 @@ int resort_state(sph_ctx *ctx) {
     hipStream_t st = ctx->stream;
     launch_set_rebuild(st, ctx->a, true);
     launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.velt);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     if (ctx->slab) launch_canon(st, ctx->c, ctx->a);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
@@ -392,7 +392,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / BOXG);      // box groups
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     ALLOC(a.slot, n > nb ? n : nb);
-    ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles); ALLOC(a.bcell_start, pad); ALLOC(a.bnear, pad);
+    ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles * SCAN_SPREAD); ALLOC(a.bcell_start, pad); ALLOC(a.bnear, pad);
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
@@ -411,6 +411,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(a.block_sums, 0, tiles * SCAN_SPREAD * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
     a.rebuild = a.flags + FLAG_REBUILD;
     a.check = a.flags + FLAG_CHECK;
@@ -437,7 +438,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemcpyAsync(bvel_in, hbv.data(), nb * sizeof(float2), hipMemcpyHostToDevice, st));
     launch_set_rebuild(st, a, true);        // the scan is a rebuild kernel
     launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.dirty, a.flags, n_boundary);
-    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild);
+    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild, true);
     launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary, bvel_in, a.bvel);
     launch_boundary_near(st, ctx->c, a);
     if (psi_given) {
@@ -600,7 +601,7 @@ int sph_update_boundary(sph_ctx *ctx, const sph_particle *boundary) {
     // follows its particle (rigid motion leaves the wall's own neighbourhood, hence psi :259, unchanged)
     launch_set_rebuild(st, a, true);
     launch_boundary_key(st, ctx->c, ctx->d_bpos_in, ctx->d_bkey, a.slot, a.count, a.dirty, a.flags, ctx->nb);
-    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild);
+    launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild, true);
     launch_boundary_reorder(st, ctx->d_bpos_in, ctx->d_bkey, a.slot, a.bcell_start, a.bpos, a.bid, ctx->nb, ctx->d_bvel_in, a.bvel);
     launch_boundary_gather_psi(st, a, ctx->d_bpsi0, ctx->nb);
     launch_boundary_near(st, ctx->c, a);
@@ -884,7 +885,7 @@ int sph_slab_step_end(sph_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     launch_halo_in(st, ctx->c, ctx->a, ctx->cap);               // rebuild step: ingest (then the next four); else ghost update
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     launch_canon(st, ctx->c, ctx->a);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);

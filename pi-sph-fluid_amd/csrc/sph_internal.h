@@ -132,6 +132,7 @@ constexpr int HALO_REC = 5;     // words per halo record
 constexpr int SCAN_ITEMS = 8;            // items per thread in the scan kernels
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;   // 2048 cells per block
+constexpr int SCAN_SPREAD = 8;           // counters per scan tile that the binning kernels add the tile's total into
 
 // ---- launchers (sph_kernels.hip); all asynchronous on `st` ----
 void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy);
@@ -158,7 +159,7 @@ void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int c
 void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 // rebuild kernels (no-ops unless flags[FLAG_REBUILD]): scan, scatter, tile records + neighbour lists
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
-                 uint32_t *block_sums, const uint32_t *rebuild);
+                 uint32_t *block_sums, const uint32_t *rebuild, bool reduce);
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 void launch_build_list(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 // variant: 0 = LDS-tiled neighbour lists (default), 1 = direct global loads over the cell ranges (A/B measurements)

@@ -188,7 +188,8 @@ DEV void key_hist_body(const Consts &c, const float2 *__restrict__ pos, const ui
                        const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs, float2 *__restrict__ velk,
                        float4 *__restrict__ pk, uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
                        uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags, uint32_t *__restrict__ dn,
-                       uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r, int chunk) {
+                       uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r, int chunk,
+                       uint32_t *__restrict__ block_sums) {
     const int t = chunk * BLK + threadIdx.x;      // chunk = 256 consecutive array slots
     const int lane = threadIdx.x & 63;
     int src0 = 0, n;
@@ -221,6 +222,22 @@ DEV void key_hist_body(const Consts &c, const float2 *__restrict__ pos, const ui
     const bool head = active && (lane == 0 || prev != key);
     const unsigned long long hm = __ballot(head);
     const unsigned long long am = __ballot(active);
+    {   // the scan's per-tile totals (2048 cells each), accumulated here so that the scan needs no reduction launch of
+        // its own: one atomic per run of equal TILES in the wave (a wave's keys span one or two tiles; one atomic per
+        // run of equal keys cost 400 us: ~300 to an address, each ~280 ns)
+        const uint32_t tkey = active ? key / SCAN_TILE : 0xffffffffu;
+        const uint32_t tprev = __shfl_up(tkey, 1, 64);
+        const bool thead = active && (lane == 0 || tprev != tkey);
+        const unsigned long long thm = __ballot(thead);
+        if (thead) {
+            const unsigned long long above = lane == 63 ? 0ull : (thm >> (lane + 1));
+            int nxt = above ? lane + 1 + __builtin_ctzll(above) : 64;
+            nxt = min(nxt, 64 - __builtin_clzll(am));
+            // (SCAN_SPREAD counters per tile, chosen by wave: a tile inside the fluid receives ~170 of these adds)
+            atomicAdd(&block_sums[tkey * SCAN_SPREAD + (((uint32_t)chunk * (BLK / 64) + (threadIdx.x >> 6)) & (SCAN_SPREAD - 1))],
+                      (uint32_t)(nxt - lane));
+        }
+    }
     if (active) {
         const unsigned long long below = hm & ((2ull << lane) - 1ull);       // run heads at or below this lane
         const int start = 63 - __builtin_clzll(below);
@@ -252,12 +269,12 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
                                                   uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
                                                   uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
                                                   const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
-                                                  int nchunks) {
+                                                  int nchunks, uint32_t *__restrict__ block_sums) {
     if (*rebuild == 0u) return;      // rebuild kernel
     // a small grid striding over the chunks: in most steps this launch returns at once, and what that costs grows with
     // the grid (1.5 us up to 2048 workgroups, 2.8 us at 8192: tools/ubench_launch)
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x)
-        key_hist_body<false>(c, pos, id, vsrc, cs, velk, pk, slot, count, dirty, flags, dn, nullptr, nullptr, chunk);
+        key_hist_body<false>(c, pos, id, vsrc, cs, velk, pk, slot, count, dirty, flags, dn, nullptr, nullptr, chunk, block_sums);
 }
 
 // the pair part of criterion (1): one thread per box group, against every group k_build_list listed for it
@@ -311,7 +328,7 @@ void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, 
     if (cap <= 0) return;
     const int nchunks = (cap + BLK - 1) / BLK;
     hipLaunchKernelGGL(k_key_hist, dim3(gated_grid(nchunks)), dim3(BLK), 0, st, c, a.pos, a.id, vsrc, a.cell_start, a.velk,
-                       a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, nchunks);
+                       a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, nchunks, a.block_sums);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,10 +379,10 @@ __global__ __launch_bounds__(BLK) void k_halo_out(Consts c, const float2 *__rest
                                                   uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
                                                   const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
                                                   uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r,
-                                                  int part_blocks, int halo_blocks) {
+                                                  int part_blocks, int halo_blocks, uint32_t *__restrict__ block_sums) {
     if (*rebuild != 0u) {
         if ((int)blockIdx.x < part_blocks)
-            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r, (int)blockIdx.x);
+            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r, (int)blockIdx.x, block_sums);
     } else if ((int)blockIdx.x < 2 * halo_blocks) {
         const int side = (int)blockIdx.x / halo_blocks;
         pack_update_body(c, side, ((int)blockIdx.x - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, send_l, send_r);
@@ -377,7 +394,7 @@ void launch_halo_out(hipStream_t st, const Consts &c, const Arrays &a, int cap) 
     const int part_blocks = (cap + BLK - 1) / BLK, halo_blocks = (c.halo_cap + BLK - 1) / BLK;
     const int grid = part_blocks > 2 * halo_blocks ? part_blocks : 2 * halo_blocks;
     hipLaunchKernelGGL(k_halo_out, dim3(grid), dim3(BLK), 0, st, c, a.pos, a.id, a.vel, a.cell_start, a.velk, a.pk, a.slot,
-                       a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1], part_blocks, halo_blocks);
+                       a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1], part_blocks, halo_blocks, a.block_sums);
 }
 
 // slab mode, rebuild step, after the scatter: put every cell of the interface columns (two ghost + two owned columns
@@ -420,7 +437,7 @@ void launch_canon(hipStream_t st, const Consts &c, const Arrays &a) {
 DEV void ingest_body(const Consts &c, const uint32_t *__restrict__ recv_l, const uint32_t *__restrict__ recv_r,
                      float2 *__restrict__ velk, float4 *__restrict__ pk, uint32_t *__restrict__ slot,
                      uint32_t *__restrict__ count, uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
-                     uint32_t *__restrict__ dn, int stage_cap) {
+                     uint32_t *__restrict__ dn, int stage_cap, uint32_t *__restrict__ block_sums) {
     const int n_own = (int)dn[1];
     const int nl = c.has_left ? min((int)recv_l[0], c.halo_cap) : 0;
     const int nr = c.has_right ? min((int)recv_r[0], c.halo_cap) : 0;
@@ -433,9 +450,29 @@ DEV void ingest_body(const Consts &c, const uint32_t *__restrict__ recv_l, const
         dn[0] = (uint32_t)total;
         if ((c.has_left && recv_l[1] != 0u) || (c.has_right && recv_r[1] != 0u)) atomicAdd(&flags[FLAG_MISMATCH], 1u);
     }
-    if (t >= nl + nr) return;
+    const bool mine = t < nl + nr && n_own + t < stage_cap;
+    {   // the scan's per-tile totals: the records of a wave fall into one or two scan tiles -> one atomic per tile and wave
+        uint32_t tkey = 0xffffffffu;
+        if (mine) {
+            const uint32_t *rr = (t < nl) ? recv_l + HALO_HDR + (size_t)t * HALO_REC : recv_r + HALO_HDR + (size_t)(t - nl) * HALO_REC;
+            int row, col;
+            bool oob, bad;
+            cell_of(c, __uint_as_float(rr[0]), __uint_as_float(rr[1]), row, col, oob, bad);
+            tkey = (uint32_t)(col * c.rows + row) / SCAN_TILE;
+        }
+        unsigned long long todo = __ballot(mine);
+        while (todo) {
+            const int lead = __builtin_ctzll(todo);
+            const uint32_t tk = (uint32_t)__shfl((int)tkey, lead, 64);
+            const unsigned long long same = __ballot(mine && tkey == tk) & todo;
+            if ((int)(threadIdx.x & 63) == lead)
+                atomicAdd(&block_sums[tk * SCAN_SPREAD + ((blockIdx.x * (BLK / 64) + (threadIdx.x >> 6)) & (SCAN_SPREAD - 1))],
+                          (uint32_t)__builtin_popcountll(same));
+            todo &= ~same;
+        }
+    }
+    if (!mine) return;
     const int dst = n_own + t;
-    if (dst >= stage_cap) return;
     const uint32_t *r = (t < nl) ? recv_l + HALO_HDR + (size_t)t * HALO_REC : recv_r + HALO_HDR + (size_t)(t - nl) * HALO_REC;
     const float2 p = make_float2(__uint_as_float(r[0]), __uint_as_float(r[1]));
     int row, col;
@@ -458,10 +495,11 @@ __global__ __launch_bounds__(BLK) void k_halo_in(Consts c, const uint32_t *__res
                                                  uint32_t *__restrict__ count, uint32_t *__restrict__ dirty,
                                                  uint32_t *__restrict__ flags, const uint32_t *__restrict__ rebuild,
                                                  uint32_t *__restrict__ dn, int stage_cap, float2 *__restrict__ pos,
-                                                 float2 *__restrict__ vel, const uint32_t *__restrict__ cs, int halo_blocks) {
+                                                 float2 *__restrict__ vel, const uint32_t *__restrict__ cs, int halo_blocks,
+                                                 uint32_t *__restrict__ block_sums) {
     if (blockIdx.x == 0 && threadIdx.x == 0) flags[FLAG_LATCH] = *rebuild;      // for the final density pass (DENS_REST)
     if (*rebuild != 0u) {
-        ingest_body(c, recv_l, recv_r, velk, pk, slot, count, dirty, flags, dn, stage_cap);
+        ingest_body(c, recv_l, recv_r, velk, pk, slot, count, dirty, flags, dn, stage_cap, block_sums);
     } else {
         const int side = (int)blockIdx.x / halo_blocks;
         unpack_update_body(c, side, ((int)blockIdx.x - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, recv_l, recv_r);
@@ -471,7 +509,7 @@ __global__ __launch_bounds__(BLK) void k_halo_in(Consts c, const uint32_t *__res
 void launch_halo_in(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap) {
     const int halo_blocks = (c.halo_cap + BLK - 1) / BLK > 0 ? (c.halo_cap + BLK - 1) / BLK : 1;
     hipLaunchKernelGGL(k_halo_in, dim3(2 * halo_blocks), dim3(BLK), 0, st, c, a.recv[0], a.recv[1], a.velk, a.pk, a.slot,
-                       a.count, a.dirty, a.flags, a.rebuild, a.dn, stage_cap, a.pos, a.vel, a.cell_start, halo_blocks);
+                       a.count, a.dirty, a.flags, a.rebuild, a.dn, stage_cap, a.pos, a.vel, a.cell_start, halo_blocks, a.block_sums);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -504,14 +542,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__re
     __shared__ uint32_t red[4];
     if (*rebuild == 0u) return;      // rebuild kernel
     if (dirty[blockIdx.x] == 0u) {      // untouched since it was last zeroed: all counts are 0
-        if (threadIdx.x == 0) block_sums[blockIdx.x] = 0u;
+        if (threadIdx.x == 0) block_sums[blockIdx.x * SCAN_SPREAD] = 0u;
         return;
     }
     const uint4 *src = reinterpret_cast<const uint4 *>(count + (size_t)blockIdx.x * SCAN_TILE) + threadIdx.x * 2;
     uint4 a = src[0], b = src[1];
     uint32_t s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+    if (threadIdx.x == 0) block_sums[blockIdx.x * SCAN_SPREAD] = s;      // (the tile's other counters are zero)
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict__ count,
@@ -524,7 +562,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
     if (*rebuild == 0u) return;      // rebuild kernel
     // offset of this tile = sum of the tiles before it (<= a few thousand L2-resident words)
     uint32_t off = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_BLOCK) off += block_sums[k];
+    for (int k = threadIdx.x; k < (int)blockIdx.x * SCAN_SPREAD; k += SCAN_BLOCK) off += block_sums[k];
     off = block_sum_256(off, red);
 
     size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
@@ -573,12 +611,20 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
     }
 }
 
+__global__ void k_zero_words(uint32_t *w, int n) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i < n) w[i] = 0u;
+}
+// reduce = false (the fluid sort of a step): the per-tile totals were accumulated by the binning kernels
+// (key_hist_body, ingest_body) and are zeroed again by k_reorder: ONE launch.  reduce = true (wall bins, at init or after
+// sph_update_boundary): the totals are computed here and zeroed afterwards.
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
-                 uint32_t *block_sums, const uint32_t *rebuild) {
+                 uint32_t *block_sums, const uint32_t *rebuild, bool reduce) {
     int n_items = c.n_cells + 1;
     int tiles = (n_items + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, dirty, block_sums, rebuild);
+    if (reduce) hipLaunchKernelGGL(k_scan_reduce, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, dirty, block_sums, rebuild);
     hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(SCAN_BLOCK), 0, st, count, block_sums, dirty, cell_start, n_items, rebuild);
+    if (reduce) hipLaunchKernelGGL(k_zero_words, dim3((tiles * SCAN_SPREAD + BLK - 1) / BLK), dim3(BLK), 0, st, block_sums, tiles * SCAN_SPREAD);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -588,9 +634,12 @@ __global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, 
                                                  const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
                                                  float2 *__restrict__ pos_ref, float2 *__restrict__ vel,
                                                  uint32_t *__restrict__ id, uint32_t *__restrict__ skey,
-                                                 const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild) {
+                                                 const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild,
+                                                 uint32_t *__restrict__ block_sums, int scan_tiles) {
     if (*rebuild == 0u) return;
     const int n = (int)dn[0];
+    // the scan has consumed its per-tile totals: leave them zero for the binning kernels of the next sort
+    for (int k = blockIdx.x * BLK + threadIdx.x; k < scan_tiles; k += gridDim.x * BLK) block_sums[k] = 0u;
     for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {      // small grid: see k_key_hist
         float4 q = pk[i];
         const uint32_t key = __float_as_uint(q.w);
@@ -604,10 +653,10 @@ __global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, 
 }
 
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
-    (void)c;
     if (cap <= 0) return;
+    const int scan_tiles = (c.n_cells + 1 + SCAN_TILE - 1) / SCAN_TILE * SCAN_SPREAD;      // counters to zero
     hipLaunchKernelGGL(k_reorder, dim3(gated_grid((cap + BLK - 1) / BLK)), dim3(BLK), 0, st, a.pk, a.velk, a.slot, a.cell_start, a.pos,
-                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.rebuild);
+                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.rebuild, a.block_sums, scan_tiles);
 }
 
 // ------------------------------------------------------------------------------------------
