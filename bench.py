@@ -332,6 +332,8 @@ def main():
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin as a fraction of 2H (default: the library's)")
     ap.add_argument("--slab-host", default="c", choices=["c", "python"],
                     help="N > 1: c = the C host over RCCL (slab_sph_fluid), python = torch.distributed (bench_slab.py)")
+    ap.add_argument("--rebalance", action="store_true",
+                    help="N > 1, python host: re-balance the slab column ranges once after the warm-up (outside the timed region)")
     ap.add_argument("--slabs-on-one-gpu", action="store_true",
                     help="run the N = 1 workload through the slab path (one slab, no exchange): its overhead")
     args = ap.parse_args()

@@ -29,9 +29,12 @@ class HostStagedTransport:
     """gloo + CPU tensors, halo buffers staged through the host (sph_slab_copy_out / _copy_in)."""
 
     def __init__(self, torch, dist, slab, rank, world):
-        self.torch, self.dist, self.slab, self.rank, self.world = torch, dist, slab, rank, world
+        self.torch, self.dist, self.slab, self.rank, self.world, self.device = torch, dist, slab, rank, world, "cpu"
         self.rl = torch.zeros(slab.words, dtype=torch.int32)
         self.rr = torch.zeros(slab.words, dtype=torch.int32)
+
+    def rebind(self, slabs):          # re-balancing: a new slab context took the place of the old one
+        self.slab = slabs[0]
 
     def reduce_flag(self):
         if self.world > 1:
@@ -61,6 +64,14 @@ class HostStagedTransport:
             self.slab.copy_in(1, self.rr.numpy().view(np.uint32))
 
 
+def _borrow_collectives(sph):
+    """the re-balancing collectives of TorchTransport work on CPU tensors over gloo as they are"""
+    T = sph.slab.TorchTransport
+    HostStagedTransport._dev = T._dev
+    HostStagedTransport.sum_over_ranks = T.sum_over_ranks
+    HostStagedTransport.redistribute = T.redistribute
+
+
 def workload_spec(sph, name, world):
     """(label, block spec, scaling, gravity source or None)"""
     if name in ("cfg2", "dam"):
@@ -78,6 +89,7 @@ def run_slabs(sph, args, emit):
     import torch
     import torch.distributed as dist
 
+    _borrow_collectives(sph)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -119,10 +131,21 @@ def run_slabs(sph, args, emit):
         slab.set_stream(stream.cuda_stream)          # kernels and RCCL ops are ordered through torch's current stream
         transport = (HostStagedTransport(torch, dist, slab, rank, world) if host_staged
                      else sph.slab.TorchTransport(torch, dist, slab, rank, world, torch.device("cuda", device)))
-        runner = sph.slab.SlabRunner(slab, transport)
+        def factory(a, z, hl, hr, loc_, ids_, gx_, gy_):
+            return sph.slab.GpuSlab(sph, prm, None, walls, a, z, hl, hr, gx_, gy_, device=device, local=(loc_, ids_))
+
+        runner = sph.slab.SlabRunner(slab, transport, factory=factory, prm=prm, rank0=rank, world=world)
         log(rank, "slab columns [%d,%d) of %d created in %.2fs, local/owned = %s" %
             (c0, c1, sph.slab.grid_columns(prm), time.time() - t0, slab.counts()))
         runner.step(args.warmup, gravity=gravity)
+        if getattr(args, "rebalance", False):
+            # dynamic re-balancing, once, outside the timed region: new column ranges from the current
+            # per-column histogram; the re-created slab adopts the stream again
+            g_now = grav.sample(sim_step[0] * dt_sim) if grav else (0.0, -9.81)
+            new_parts = runner.rebalance(g_now[0], g_now[1], min_gain=0.0)
+            runner.slabs[0].set_stream(stream.cuda_stream)
+            slab = runner.slabs[0]
+            log(rank, "re-balanced: columns", new_parts[rank] if new_parts else "unchanged", "local/owned =", slab.counts())
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()

@@ -279,10 +279,11 @@ int check_flags(sph_ctx *ctx) {
         ctx->oob_total += h[FLAG_OOB];
         ctx->nan_total += h[FLAG_NAN];
         if (h[FLAG_NAN]) return fail(ctx, SPH_E_NAN, "particle positions became NaN/Inf");
+        // (capacity first: a slab that dropped particles also puts its neighbours out of step)
+        if (h[FLAG_CAPACITY]) return fail(ctx, SPH_E_CAPACITY, "slab particle or halo capacity exceeded");
         if (h[FLAG_MISMATCH])
             return fail(ctx, SPH_E_STATE, "halo message does not match this step (neighbouring slabs out of step, or the rebuild "
                                           "word was not reduced over all ranks before sph_slab_step_pack)");
-        if (h[FLAG_CAPACITY]) return fail(ctx, SPH_E_CAPACITY, "slab particle or halo capacity exceeded");
         return fail(ctx, SPH_E_OUT_OF_DOMAIN, ctx->slab ? "particles left the slab's local grid and were clamped into edge cells"
                                                         : "particles left the domain and were clamped into edge cells");
     }

@@ -261,6 +261,18 @@ class LocalTransport:
     def __init__(self, slabs):
         self.slabs = slabs
 
+    # re-balancing (SlabRunner.rebalance): the "ranks" are the slabs of this process
+    def rebind(self, slabs):
+        self.slabs = slabs
+
+    def sum_over_ranks(self, per_slab_arrays):
+        return np.sum(per_slab_arrays, axis=0)
+
+    def redistribute(self, outgoing):
+        """outgoing[r][q] = record array slab r sends to slab q  ->  incoming[q] = everything sent to q"""
+        n = len(outgoing)
+        return [np.concatenate([outgoing[r][q] for r in range(n)]) for q in range(n)]
+
     def reduce_flag(self):
         s = self.slabs
         if len(s) > 1:
@@ -289,9 +301,48 @@ class TorchTransport:
     two of a GPU's seven xGMI links carry traffic and the messages are latency-bound."""
 
     def __init__(self, torch, dist, slab, rank, world, device):
-        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
-        self.send_l, self.send_r, self.recv_l, self.recv_r = slab.halo_tensors(torch, device)
-        self.flag = slab.flag_tensor(torch, device)
+        self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
+        self.rebind([slab])
+
+    # re-balancing (SlabRunner.rebalance): one slab per rank
+    def rebind(self, slabs):
+        slab = slabs[0]
+        self.send_l, self.send_r, self.recv_l, self.recv_r = slab.halo_tensors(self.torch, self.device)
+        self.flag = slab.flag_tensor(self.torch, self.device)
+
+    def _dev(self, t):
+        return t.to(self.device) if str(self.device) != "cpu" else t
+
+    def sum_over_ranks(self, per_slab_arrays):
+        t = self._dev(self.torch.from_numpy(np.ascontiguousarray(per_slab_arrays[0], np.int64)))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def redistribute(self, outgoing):
+        """outgoing[0][q] = float32 record array (k x RECW) this rank sends to rank q -> [everything sent to this rank]"""
+        t, d = self.torch, self.dist
+        mine = outgoing[0]
+        counts = t.tensor([len(a) for a in mine], dtype=t.int64)
+        allc = [self._dev(t.zeros(self.world, dtype=t.int64)) for _ in range(self.world)]
+        d.all_gather(allc, self._dev(counts))
+        allc = [c.cpu() for c in allc]                      # allc[r][q] = records r sends to q
+        width = mine[0].shape[1] if mine[0].ndim == 2 else 0
+        recv = [t.zeros((int(allc[r][self.rank]), width), dtype=t.float32) for r in range(self.world)]
+        recv = [self._dev(x) for x in recv]
+        ops, keep = [], []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            if len(mine[q]):
+                buf = self._dev(t.from_numpy(np.ascontiguousarray(mine[q], np.float32)))
+                keep.append(buf)
+                ops.append(d.P2POp(d.isend, buf, q))
+            if recv[q].shape[0]:
+                ops.append(d.P2POp(d.irecv, recv[q], q))
+        for w in (d.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        parts = [mine[self.rank]] + [recv[q].cpu().numpy() for q in range(self.world) if q != self.rank]
+        return [np.concatenate(parts)]
 
     def reduce_flag(self):
         """all slabs rebuild in the same step: MAX over ranks of the 4-byte rebuild word (stays on the device)."""
@@ -321,9 +372,13 @@ class SlabRunner:
     """nsteps of: kick/drift -> reduce the rebuild word -> halo pack -> exchange (beside it: density of the interior
     tiles) -> (ingest + sort + lists | ghost update) + density of the rest + force (pi_sph_fluid.c:612-641)."""
 
-    def __init__(self, slabs, transport, overlap=None):
+    def __init__(self, slabs, transport, overlap=None, factory=None, prm=None, rank0=0, world=None):
+        """factory(c0, c1, has_left, has_right, particles, ids, gx, gy) -> a new slab: needed only by rebalance(), with
+        prm (the scene's parameters), rank0 (global index of this process's first slab) and world (slabs in total)."""
         self.slabs = slabs if isinstance(slabs, (list, tuple)) else [slabs]
         self.transport = transport
+        self.factory, self.prm, self.rank0 = factory, prm, rank0
+        self.world = world if world is not None else len(self.slabs)
         # splitting the density pass costs one more launch: worth it only when there is an exchange to hide
         self.overlap = (len(self.slabs) > 1 or getattr(transport, "world", 1) > 1) if overlap is None else overlap
 
@@ -345,6 +400,57 @@ class SlabRunner:
             self.transport.exchange_finish(handle)
             for s in self.slabs:
                 s.step_end()
+
+    RECW = 8      # words per particle in a re-balancing message: x, y, u, v, m, rho, p, id (bits)
+
+    def rebalance(self, gx=0.0, gy=-9.81, min_gain=0.05):
+        """Dynamic re-balancing: new column ranges from the CURRENT per-column particle histogram
+        (summed over all ranks), every particle moved to the slab that now holds its column (owned + 2 ghost columns),
+        the slab contexts re-created from them.  Collective: every rank calls it between two steps.  A re-created
+        context evaluates rho, p, a from (x, v) like the reference's init sequence (:604-607) — the checkpoint / resume
+        semantics of SURVEY.md 5 — so the run is continued, not bit-continued.  Returns the new column ranges, or None
+        when the largest slab would shrink by less than min_gain (nothing is touched then)."""
+        if self.factory is None or self.prm is None:
+            raise ValueError("SlabRunner.rebalance needs factory= and prm=")
+        prm, world = self.prm, self.world
+        cols = grid_columns(prm)
+        owned = [s.read()[:2] for s in self.slabs]                                   # (particles, ids) per local slab
+        hists = [np.bincount(np.clip(global_columns(prm, p["x"]), 0, cols - 1), minlength=cols).astype(np.int64) for p, _ in owned]
+        per_slab_counts = []
+        for k, (p, _) in enumerate(owned):
+            v = np.zeros(world, np.int64)
+            v[self.rank0 + k] = len(p)
+            per_slab_counts.append(v)
+        hist = np.asarray(self.transport.sum_over_ranks(hists)).reshape(-1)          # particles per global column, all ranks
+        counts = np.asarray(self.transport.sum_over_ranks(per_slab_counts)).reshape(-1)      # owned particles per slab
+        parts = _cuts_from_histogram(hist, world, 0, cols)
+        cum = np.concatenate([[0], np.cumsum(hist)])
+        new_counts = np.array([cum[c1] - cum[c0] for c0, c1 in parts])
+        if counts.max() - new_counts.max() < min_gain * max(counts.max(), 1):
+            return None
+        outgoing = []
+        for p, ids in owned:
+            gc = global_columns(prm, p["x"])
+            rec = np.zeros((len(p), self.RECW), np.float32)
+            for j, fld in enumerate(("x", "y", "u", "v", "m", "rho", "p")):
+                rec[:, j] = p[fld]
+            rec[:, 7] = ids.astype(np.uint32).view(np.float32)
+            outgoing.append([rec[(gc >= c0 - GHOST) & (gc < c1 + GHOST)] for c0, c1 in parts])
+        incoming = self.transport.redistribute(outgoing)
+        for s in self.slabs:
+            s.close()
+        new = []
+        for k, rec in enumerate(incoming):
+            r = self.rank0 + k
+            c0, c1 = parts[r]
+            loc = np.zeros(len(rec), owned[0][0].dtype)
+            for j, fld in enumerate(("x", "y", "u", "v", "m", "rho", "p")):
+                loc[fld] = rec[:, j]
+            ids = np.ascontiguousarray(rec[:, 7]).view(np.uint32).copy()
+            new.append(self.factory(c0, c1, r > 0, r < world - 1, loc, ids, gx, gy))
+        self.slabs = new
+        self.transport.rebind(new)
+        return parts
 
     def gather_local(self, n_total, particle_dtype):
         """all slabs of THIS process merged back into original order (ids index the global arrays)."""

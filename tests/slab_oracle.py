@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 class OracleSlab:
-    def __init__(self, sph, orc, O, prm, fluid, boundary_psi, c0, c1, has_left, has_right, gx, gy, halo_capacity):
+    def __init__(self, sph, orc, O, prm, fluid, boundary_psi, c0, c1, has_left, has_right, gx, gy, halo_capacity, local=None):
         self.sph, self.orc, self.O, self.prm = sph, orc, O, prm
         self.p = O.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
         self.b = boundary_psi
@@ -27,8 +27,11 @@ class OracleSlab:
         self.bufs = [np.zeros(words, np.uint32) for _ in range(4)]     # send_l, send_r, recv_l, recv_r
         self.half_dt = 0.5 * float(np.float32(prm.dt))                  # 0.5*DT in double (:616)
         self.dt = np.float32(prm.dt)
-        loc, ids = sph.slab.local_subset(prm, fluid, c0, c1)
+        loc, ids = local if local is not None else sph.slab.local_subset(prm, fluid, c0, c1)
         self._evaluate(loc.view(orc.PARTICLE).copy(), ids, gx, gy, second_kick=False)
+
+    def close(self):
+        pass
 
     def _evaluate(self, loc, ids, gx, gy, second_kick):
         order = np.argsort(ids, kind="stable")
@@ -106,7 +109,7 @@ class OracleSlab:
         return self.own, self.ids, self.du, self.dv
 
 
-def gloo_worker(rank, world, port, scene, nsteps, q):
+def gloo_worker(rank, world, port, scene, nsteps, q, rebalance_at=0):
     """one gloo rank: build my slab, run the product's SlabRunner over TorchTransport, report my particles."""
     import torch
     import torch.distributed as dist
@@ -123,10 +126,25 @@ def gloo_worker(rank, world, port, scene, nsteps, q):
         c0, c1 = parts[rank]
         slab = OracleSlab(sph, orc, O, prm, f, bp, c0, c1, rank > 0, rank < world - 1, 0.0, -9.81,
                           sph.slab.default_halo_capacity(prm))
-        runner = sph.slab.SlabRunner(slab, sph.slab.TorchTransport(torch, dist, slab, rank, world, "cpu"))
+        cap = sph.slab.default_halo_capacity(prm)
+
+        def factory(a, z, hl, hr, loc, ids, gx, gy):
+            return OracleSlab(sph, orc, O, prm, None, bp, a, z, hl, hr, gx, gy, cap, local=(loc, ids))
+
+        runner = sph.slab.SlabRunner(slab, sph.slab.TorchTransport(torch, dist, slab, rank, world, "cpu"),
+                                     factory=factory, prm=prm, rank0=rank, world=world)
         migrated = 0
         before = set(slab.ids.tolist())
-        runner.step(nsteps, 0.0, -9.81)
+        new_parts = None
+        if rebalance_at:
+            runner.step(rebalance_at, 0.0, -9.81)
+            new_parts = runner.rebalance(0.0, -9.81, min_gain=0.0)
+            runner.step(nsteps - rebalance_at, 0.0, -9.81)
+        else:
+            runner.step(nsteps, 0.0, -9.81)
+        slab = runner.slabs[0]
+        if new_parts:
+            c0, c1 = new_parts[rank]
         own, ids, du, dv = slab.read()
         migrated = len(set(ids.tolist()) - before)
         q.put((rank, own, ids, du, dv, migrated, (c0, c1)))

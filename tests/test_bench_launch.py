@@ -40,6 +40,11 @@ def test_self_launch_two_ranks_on_one_gpu(sph):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["particles_conserved"] is True
     assert out["config"]["n_fluid"] == 4000000 and out["value"] > 0 and out["scaling"] == "weak"
+    # and with a re-balancing of the column ranges after the warm-up (collectives over gloo, slab contexts re-created)
+    r = subprocess.run(CMD + ["--rebalance"], capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert out["particles_conserved"] is True and b"re-balanced" in r.stderr
 
 
 def test_c_host_path_fails_loudly_without_gpu(sph):

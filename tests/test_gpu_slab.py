@@ -175,3 +175,62 @@ def test_step_overlap_is_optional(sph, orc):
     for other in res[1:]:
         assert np.max(np.abs(other["x"] - res[0]["x"])) <= 5e-5 and np.max(np.abs(other["y"] - res[0]["y"])) <= 5e-5      # two RUNS of a chaotic flow (atomic arrival order): 2.1e-5 seen
         assert np.max(np.abs(other["rho"] - res[0]["rho"]) / res[0]["rho"]) <= 2e-4
+
+
+def test_rebalance_keeps_a_migrating_flow_inside_capacity(sph):
+    """dynamic re-balancing: a block flying along x at 30 m/s leaves the first slab and piles into the
+    last one.  With the static partition the last slab runs out of particle capacity (SPH_E_CAPACITY, reported, not
+    UB); with SlabRunner.rebalance() every 150 steps the run goes through, every particle stays owned exactly once,
+    the slabs stay balanced, and the result is the single context's (a re-created slab re-evaluates a from (x, v): the
+    run is continued, not bit-continued; the block moves as a whole, so the comparison is tight)."""
+    prm, f, b = sph.scene_block((0.0, 60.0, 0.0, 6.0), 2.0, 1.5, 160, 40)
+    f["u"] = 30.0
+    world, nsteps = 3, 900
+    parts = sph.slab.partition_columns(prm, f, world)
+
+    def factory(c0, c1, hl, hr, loc, ids, gx, gy):      # capacity: a third of the particles + 50 % (the default is generous for small scenes)
+        return sph.slab.GpuSlab(sph, prm, None, b, c0, c1, hl, hr, gx, gy, local=(loc, ids), particle_capacity=len(f) // 2)
+
+    def make():
+        slabs = [factory(c0, c1, r > 0, r < world - 1, *sph.slab.local_subset(prm, f, c0, c1), GX, GY) for r, (c0, c1) in enumerate(parts)]
+        return slabs, sph.slab.SlabRunner(slabs, sph.slab.LocalTransport(slabs), factory=factory, prm=prm, world=world)
+
+    # static partition: the last slab overflows
+    slabs, runner = make()
+    codes = []
+    for _ in range(nsteps // 50):
+        runner.step(50, GX, GY)
+        for s in runner.slabs:
+            try:
+                s.sync()
+            except sph.SphError as e:
+                codes.append(e.code)
+        if codes:
+            break
+    assert sph.SPH_E_CAPACITY in codes, codes       # (its neighbours may report SPH_E_STATE: out of step with it)
+    for s in runner.slabs:
+        s.close()
+    # re-balanced every 150 steps
+    slabs, runner = make()
+    moved = 0
+    for k in range(nsteps // 150):
+        runner.step(150, GX, GY)
+        for s in runner.slabs:
+            s.sync()
+        new = runner.rebalance(GX, GY)
+        if new is not None:
+            moved += 1
+            owned = [s.counts()[1] for s in runner.slabs]
+            assert sum(owned) == len(f) and max(owned) - min(owned) <= 0.05 * len(f)
+    assert moved >= 3
+    out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+    assert np.all(seen == 1)
+    for s in runner.slabs:
+        s.close()
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.step(nsteps, GX, GY)
+        ctx.sync()
+        ref = ctx.read_particles()
+    assert np.abs(ref["x"] - f["x"]).min() > 5.0                                  # the block really travelled
+    assert max(np.abs(out["x"] - ref["x"]).max(), np.abs(out["y"] - ref["y"]).max()) <= 2e-4
+    assert np.max(np.abs(out["rho"] - ref["rho"]) / ref["rho"]) <= 1e-3

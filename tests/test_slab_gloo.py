@@ -20,11 +20,11 @@ def free_port():
     return p
 
 
-def run_world(world, scene, nsteps):
+def run_world(world, scene, nsteps, rebalance_at=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=slab_oracle.gloo_worker, args=(r, world, port, scene, nsteps, q)) for r in range(world)]
+    procs = [ctx.Process(target=slab_oracle.gloo_worker, args=(r, world, port, scene, nsteps, q, rebalance_at)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -57,6 +57,38 @@ def test_slabs_equal_single_rank_bit_exact(sph, orc, oracle, world, scene, nstep
     assert np.all(seen == 1)                              # every particle owned exactly once
     if scene == "block_moving":
         assert migrated > 0                               # the test really exercised migration
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rebalance_over_gloo(sph, orc, oracle, world):
+    """dynamic re-balancing with one slab per rank: after 70 steps of a block flying sideways (two cell columns) the ranks
+    re-partition from the current column histogram, ship every particle to the slab that now holds its column and
+    continue; the merged result is the single-rank oracle's to rounding (a re-created slab re-evaluates a from (x, v),
+    the reference's init sequence: continued, not bit-continued), nothing lost or duplicated, ownership by position."""
+    nsteps, at = 100, 70
+    prm, f, b = slab_oracle.scene_build(sph, "block_moving")
+    p = oracle.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
+    of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()
+    oracle.psi(p, ob)
+    du, dv = oracle.eval(p, of, ob, 0.0, -9.81, threads=2)
+    oracle.steps(p, of, ob, 0.0, -9.81, du, dv, nsteps, threads=2)
+    res = run_world(world, "block_moving", nsteps, rebalance_at=at)
+    seen = np.zeros(len(f), int)
+    ranges = []
+    for rank, own, ids, sdu, sdv, mig, (c0, c1) in res:
+        seen[ids] += 1
+        ranges.append((c0, c1))
+        assert max(np.abs(own["x"] - of["x"][ids]).max(), np.abs(own["y"] - of["y"][ids]).max()) <= 5e-6
+        assert np.max(np.abs(own["rho"] - of["rho"][ids]) / of["rho"][ids]) <= 1e-5
+        gc = sph.slab.global_columns(prm, own["x"])
+        assert np.all((gc >= c0) & (gc < c1))
+    assert np.all(seen == 1)
+    assert ranges[0][0] == 0 and all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+    first = sph.slab.partition_columns(prm, f, world, slack=8)
+    assert [z for _, z in ranges[:-1]] != [z for _, z in first[:-1]]            # the cuts followed the block
+    assert ranges[-1][1] == sph.slab.grid_columns(prm)                           # and the slabs now tile the whole box
+    counts = [len(r[1]) for r in res]
+    assert max(counts) - min(counts) <= 0.25 * len(f) / world                    # balanced again (30 steps later)
 
 
 def test_partition_and_halo_format(sph):
