@@ -398,6 +398,7 @@ def main():
         out["also"].append({"workload": "cfg2, developed flow: steps %d-%d of the same run" % (late_warm, late_warm + args.steps),
                             "value": round(r2["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
                             "timesteps_per_s": round(r2["steps_per_s"], 2), "ms_per_step": round(r2["ms_per_step"], 5),
+                            "kernel_ms": {k: round(v, 5) for k, v in r2["kernel_ms"].items()},
                             "neighbour_rebuilds_per_step": round(r2["timed_rebuilds_per_step"], 4),
                             "max_speed": round(r2["max_speed"], 2),
                             "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r2["n_fluid"] * r2["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)})

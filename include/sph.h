@@ -149,6 +149,9 @@ int  sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell);
  * The skin is sph_params.skin (a fraction of 2H, 0 <= skin <= 1), fixed per context at creation. */
 /* cell length of the device grid for these parameters: 2H (1 + skin) — what slab hosts must bin with */
 float sph_device_cell(const sph_params *prm);
+/* ask for a rebuild of the neighbour structure in the next step whatever the displacement criterion says (measurement;
+ * hosts that want the reference's rebuild-every-step behaviour for a while without re-creating the context) */
+int   sph_request_rebuild(sph_ctx *ctx);
 /* rebuilds since creation, and tiles that list builds have put on the direct (no list) path */
 int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
 /* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */

@@ -653,6 +653,14 @@ float sph_device_cell(const sph_params *prm) {
     const float two_h = 2 * prm->h;
     return two_h + prm->skin * two_h;      // the arithmetic of make_consts
 }
+int sph_request_rebuild(sph_ctx *ctx) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: raise the word with sph_slab_flag_set on every rank");
+    (void)hipSetDevice(ctx->device);
+    launch_request_rebuild(ctx->stream, ctx->a);
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
 int sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);

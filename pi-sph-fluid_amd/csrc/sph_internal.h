@@ -140,6 +140,8 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy);
 // read on the device from a.dn[0], so slab mode (count changes every step) and single mode share the kernels.
 // set / clear flags[FLAG_REBUILD] from the host side of the stream
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
+// raise the rebuild request: the next step rebuilds the neighbour structure
+void launch_request_rebuild(hipStream_t st, const Arrays &a);
 // first half kick + drift in place (:615-624; slab mode: the owned range); requests a rebuild when the lists may be stale
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab);
 // slab mode: fill the send buffers — rebuild step: keys + histogram of the owned range into the staging arrays + full

@@ -74,6 +74,9 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy) {
 }
 
 __global__ void k_set_word(uint32_t *word, uint32_t value) { *word = value; }
+void launch_request_rebuild(hipStream_t st, const Arrays &a) {
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, 1u);
+}
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
     hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, on ? 1u : 0u);
     if (!on) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.check, 0u);

@@ -29,5 +29,13 @@ for abl in (("0", "1", "2", "4", "7", "8", "15", "16", "31", "32", "63", "0") if
     os.environ["SPH_ABLATE"] = abl
     print("force SPH_ABLATE=%s : %.2f us" % (abl, ctx.time_kernel("force_kick", 50) * 1e3))
 os.environ.pop("SPH_ABLATE", None)
+# what a rebuild costs: a rebuild requested before every step, per-kernel times by HIP events
+acc = {}
+for _ in range(10):
+    ctx.request_rebuild()
+    kt = ctx.profile_steps(1)
+    for k, v in kt.items():
+        acc[k] = acc.get(k, 0.0) + v / 10
+print("rebuild every step:", {k: round(v * 1e3, 1) for k, v in acc.items() if k not in ("rebuilds_per_step",)}, "rebuilds/step", acc["rebuilds_per_step"])
 ctx.step(1)
 ctx.sync()
