@@ -178,7 +178,9 @@ int  sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_
  * events on the context's stream.  Only the idempotent kernels (SPH_K_DENSITY_EOS, SPH_K_FORCE_KICK: same
  * inputs -> same outputs, nothing they read is overwritten) can be timed this way; others give SPH_E_ARG.
  * SPH_K_FORCE_KICK re-does the kick of the last step: valid only after at least one sph_step since creation / upload /
- * sph_eval_accel (SPH_E_STATE otherwise: the velocities would be kicked a second time). */
+ * sph_eval_accel (SPH_E_STATE otherwise: the velocities would be kicked a second time).  SPH_K_BUILD_LIST (single-GPU
+ * contexts) rebuilds the lists on the sort that is there and leaves the rebuild request raised, so the next step
+ * redoes the whole neighbour structure. */
 int  sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms);
 /* adopt an existing hipStream_t (e.g. the host framework's current stream); NULL = own stream */
 int  sph_set_stream(sph_ctx *ctx, void *hip_stream);
@@ -186,6 +188,13 @@ int  sph_set_stream(sph_ctx *ctx, void *hip_stream);
 size_t sph_device_bytes(const sph_ctx *ctx);
 /* select kernel variant for density/force: 0 = default (best), others for A/B measurements */
 int  sph_set_variant(sph_ctx *ctx, int variant);
+/* How a step launches its rebuild chain (binning, scan, scatter, lists): one_launch = 1 (default of single-GPU contexts):
+ * ONE kernel with grid barriers between the phases, sized to what the device holds at once, so that the many steps
+ * that rebuild nothing pay for one empty launch instead of four.  It needs the device to itself: if another process
+ * keeps compute units busy with a kernel that does not end, a barrier gives up after a few seconds and the next call
+ * that checks the flags returns SPH_E_STATE.  one_launch = 0: one kernel per phase (always the case for slab
+ * contexts, which may share a device).  Results are the same either way. */
+int  sph_set_rebuild_launches(sph_ctx *ctx, int one_launch);
 
 /* ---- multi-GPU: x-slab domain decomposition, one process per GPU ----
  * The reference has no distributed path; this is the sharding of its particle loops (:272, :311) by cell column.

@@ -54,6 +54,7 @@ struct sph_ctx {
     hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};          // [0,1]: one step; [2,3]: MULTI_STEPS steps
     hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
     bool use_graph = true;
+    int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
     long long oob_total = 0, nan_total = 0;
     std::string err;
@@ -160,13 +161,17 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
     if (!ctx->slab) launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2: do neighbouring waves still move together?
-    launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
-    if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
-    if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
-    launch_reorder(st, ctx->c, ctx->a, ctx->cap);
-    if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
-    launch_build_list(st, ctx->c, ctx->a, ctx->cap);
+    if (ctx->rebuild_wgs > 0 && !ev) {
+        launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs);
+    } else {       // (the profiled step, and contexts that may share their device: one kernel per phase)
+        launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
+        if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
+        launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
+        if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
+        launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+        if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
+        launch_build_list(st, ctx->c, ctx->a, ctx->cap);
+    }
     if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true);
     if (ev) (void)hipEventRecord(ev[SPH_K_FORCE_KICK], st);
@@ -272,6 +277,13 @@ int check_flags(sph_ctx *ctx) {
     uint32_t h[FLAG_COUNT] = {0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[FLAG_BAR_TIMEOUT]) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_BAR_TIMEOUT, 0, sizeof(uint32_t), ctx->stream));
+        ctx->rebuild_wgs = 0;
+        drop_graph(ctx);
+        return fail(ctx, SPH_E_STATE, "the one-launch rebuild gave up at a grid barrier: its workgroups were not all resident (is another "
+                                      "process computing on this device?); the state is invalid, upload it again");
+    }
     if (h[FLAG_OOB] | h[FLAG_NAN] | h[FLAG_CAPACITY] | h[FLAG_MISMATCH]) {
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags, 0, 2 * sizeof(uint32_t), ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_CAPACITY, 0, sizeof(uint32_t), ctx->stream));
@@ -397,6 +409,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
+    ALLOC(a.gbar, (size_t)GBAR_WORDS * GBAR_STRIDE);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 1024);
     ALLOC(ctx->d_ids, n);
     float2 *&bpos_in = ctx->d_bpos_in, *&bvel_in = ctx->d_bvel_in;
@@ -409,11 +422,13 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         ctx->own_halo = true;
     }
 #undef ALLOC
+    if (!slab) ctx->rebuild_wgs = rebuild_grid(ctx->device, ctx->cap);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.block_sums, 0, tiles * SCAN_SPREAD * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(a.gbar, 0, sizeof(uint32_t) * (size_t)GBAR_WORDS * GBAR_STRIDE, st));
     a.rebuild = a.flags + FLAG_REBUILD;
     a.check = a.flags + FLAG_CHECK;
     a.latch = a.flags + FLAG_LATCH;
@@ -687,6 +702,17 @@ long long sph_out_of_domain_count(sph_ctx *ctx) {
 }
 size_t sph_device_bytes(const sph_ctx *ctx) { return ctx ? ctx->bytes : 0; }
 
+int sph_set_rebuild_launches(sph_ctx *ctx, int one_launch) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (ctx->slab && one_launch) return fail(ctx, SPH_E_STATE, "slab contexts rebuild with one kernel per phase");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graph(ctx);
+    ctx->rebuild_wgs = one_launch ? rebuild_grid(ctx->device, ctx->cap) : 0;
+    if (one_launch && ctx->rebuild_wgs <= 0) return fail(ctx, SPH_E_HIP, "occupancy query for the one-launch rebuild failed");
+    return SPH_OK;
+}
+
 int sph_set_variant(sph_ctx *ctx, int variant) {
     if (!ctx || variant < 0 || variant > 1) return SPH_E_ARG;
     if (variant != ctx->variant) {
@@ -821,15 +847,21 @@ int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_t
 
 int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     if (!ctx || !ctx->stream || !ms || reps <= 0) return SPH_E_ARG;
-    if (kernel != SPH_K_DENSITY_EOS && kernel != SPH_K_FORCE_KICK) return fail(ctx, SPH_E_ARG, "sph_time_kernel: kernel is not idempotent");
+    if (kernel != SPH_K_DENSITY_EOS && kernel != SPH_K_FORCE_KICK && kernel != SPH_K_BUILD_LIST)
+        return fail(ctx, SPH_E_ARG, "sph_time_kernel: kernel is not idempotent");
+    if (kernel == SPH_K_BUILD_LIST && ctx->slab) return fail(ctx, SPH_E_STATE, "sph_time_kernel(SPH_K_BUILD_LIST): not on a slab context");
     // the force pass of the step writes velt = vel + dt/2 a: a repeat of the last step's kick only once a step has
     // kicked vel; before that vel == velt and the launch would kick the velocities a second time
     if (kernel == SPH_K_FORCE_KICK && !ctx->stepped)
         return fail(ctx, SPH_E_STATE, "sph_time_kernel(SPH_K_FORCE_KICK) needs at least one sph_step since creation / upload");
     (void)hipSetDevice(ctx->device);
+    // the list build on the sort that is there, with the positions of now: what it leaves is replaced by the next step,
+    // which finds the rebuild word raised
+    if (kernel == SPH_K_BUILD_LIST) launch_request_rebuild(ctx->stream, ctx->a);
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int r = 0; r < reps; r++) {
-        if (kernel == SPH_K_DENSITY_EOS) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false);
+        if (kernel == SPH_K_BUILD_LIST) launch_build_list(ctx->stream, ctx->c, ctx->a, ctx->cap);
+        else if (kernel == SPH_K_DENSITY_EOS) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false);
         else launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

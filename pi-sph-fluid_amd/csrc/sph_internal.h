@@ -86,6 +86,7 @@ struct Arrays {
     // misc
     float2 *grav;       // gravity vector read by the force kernel
     uint32_t *flags;    // see FLAG_*
+    uint32_t *gbar;     // k_rebuild's grid barrier: GBAR_WORDS words, GBAR_STRIDE apart (arrivals, one per XCD, releases)
     float4 *wbox;       // per group of BOXG consecutive sorted particles: bounding box of displacement since the last rebuild
     uint32_t *wnbr;     // per group: WNBR_WORDS words = 5 x {first, last} group whose particles may come near this group's
     uint32_t *latch;    // slab mode: copy of the reduced rebuild word of the current step (flags + FLAG_LATCH)
@@ -110,7 +111,8 @@ enum {
     FLAG_CHECK = 9,         // set by the drifting kernel: a particle is beyond skin/2, the wave boxes need comparing
     FLAG_NCHECK = 10,       // steps in which k_check ran
     FLAG_LATCH = 11,        // slab mode: the reduced rebuild word of this step, latched by k_halo_in for the final density pass
-    FLAG_COUNT = 12
+    FLAG_BAR_TIMEOUT = 12,  // k_rebuild: a grid barrier gave up waiting (its workgroups were not all resident)
+    FLAG_COUNT = 13
 };
 constexpr int TILE_WORDS = 32;           // 32-bit words per tile record
 constexpr int WNBR_WORDS = 10;           // words per box group in Arrays::wnbr
@@ -129,6 +131,8 @@ constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle lis
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record
 
+constexpr int GBAR_MAX_WGS = 2048, GBAR_COPIES = 32, GBAR_STRIDE = 32;      // (words: 128 bytes apart)
+constexpr int GBAR_WORDS = GBAR_MAX_WGS + 8 + 8 * GBAR_COPIES + 8;      // arrivals, written back (per XCD), go (per XCD, in copies), leaders' XCDs
 constexpr int SCAN_ITEMS = 8;            // items per thread in the scan kernels
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;   // 2048 cells per block
@@ -140,6 +144,10 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy);
 // read on the device from a.dn[0], so slab mode (count changes every step) and single mode share the kernels.
 // set / clear flags[FLAG_REBUILD] from the host side of the stream
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
+// the whole rebuild chain of a step (binning, scan, scatter, tile records + lists) as ONE launch with grid barriers
+// between the phases: `grid` workgroups, all resident at once (rebuild_grid).  A no-op unless the rebuild word is set.
+int rebuild_grid(int device, int cap);
+void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid);
 // raise the rebuild request: the next step rebuilds the neighbour structure
 void launch_request_rebuild(hipStream_t st, const Arrays &a);
 // first half kick + drift in place (:615-624; slab mode: the owned range); requests a rebuild when the lists may be stale

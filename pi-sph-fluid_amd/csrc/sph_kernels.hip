@@ -555,21 +555,18 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(const uint32_t *__re
     if (threadIdx.x == 0) block_sums[blockIdx.x * SCAN_SPREAD] = s;      // (the tile's other counters are zero)
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict__ count,
-                                                           const uint32_t *__restrict__ block_sums,
-                                                           uint32_t *__restrict__ dirty,
-                                                           uint32_t *__restrict__ cell_start, int n_items,
-                                                           const uint32_t *__restrict__ rebuild) {
+// one tile (SCAN_TILE entries) of the exclusive scan, by a workgroup of SCAN_BLOCK threads
+DEV void scan_apply_tile(const int tile, uint32_t *__restrict__ count, const uint32_t *__restrict__ block_sums,
+                         uint32_t *__restrict__ dirty, uint32_t *__restrict__ cell_start, int n_items) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t wave_tot[4];
-    if (*rebuild == 0u) return;      // rebuild kernel
     // offset of this tile = sum of the tiles before it (<= a few thousand L2-resident words)
     uint32_t off = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x * SCAN_SPREAD; k += SCAN_BLOCK) off += block_sums[k];
+    for (int k = threadIdx.x; k < tile * SCAN_SPREAD; k += SCAN_BLOCK) off += block_sums[k];
     off = block_sum_256(off, red);
 
-    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    if (dirty[blockIdx.x] == 0u) {      // empty tile: every cell starts at the running offset; nothing to read or zero
+    size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    if (dirty[tile] == 0u) {      // empty tile: every cell starts at the running offset; nothing to read or zero
         if (base + SCAN_ITEMS <= (size_t)n_items) {
             uint4 *dst = reinterpret_cast<uint4 *>(cell_start + base);
             dst[0] = make_uint4(off, off, off, off);
@@ -582,7 +579,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
         return;
     }
     __syncthreads();                    // every thread has read the flag before it is cleared
-    if (threadIdx.x == 0) dirty[blockIdx.x] = 0u;
+    if (threadIdx.x == 0) dirty[tile] = 0u;
     uint4 *src = reinterpret_cast<uint4 *>(count + base);
     uint4 a = src[0], b = src[1];
     uint32_t v[SCAN_ITEMS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -614,6 +611,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict_
     }
 }
 
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(uint32_t *__restrict__ count,
+                                                           const uint32_t *__restrict__ block_sums,
+                                                           uint32_t *__restrict__ dirty,
+                                                           uint32_t *__restrict__ cell_start, int n_items,
+                                                           const uint32_t *__restrict__ rebuild) {
+    if (*rebuild == 0u) return;      // rebuild kernel
+    scan_apply_tile((int)blockIdx.x, count, block_sums, dirty, cell_start, n_items);
+}
+
 __global__ void k_zero_words(uint32_t *w, int n) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i < n) w[i] = 0u;
@@ -632,15 +638,10 @@ void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dir
 
 // ------------------------------------------------------------------------------------------
 // P4: scatter to cell order (rebuild kernel).  The sorted positions are the reference positions of the new lists.
-__global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, const float2 *__restrict__ velk,
-                                                 const uint32_t *__restrict__ slot,
-                                                 const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
-                                                 float2 *__restrict__ pos_ref, float2 *__restrict__ vel,
-                                                 uint32_t *__restrict__ id, uint32_t *__restrict__ skey,
-                                                 const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild,
-                                                 uint32_t *__restrict__ block_sums, int scan_tiles) {
-    if (*rebuild == 0u) return;
-    const int n = (int)dn[0];
+DEV void reorder_body(const float4 *__restrict__ pk, const float2 *__restrict__ velk, const uint32_t *__restrict__ slot,
+                      const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos, float2 *__restrict__ pos_ref,
+                      float2 *__restrict__ vel, uint32_t *__restrict__ id, uint32_t *__restrict__ skey, const int n,
+                      uint32_t *__restrict__ block_sums, const int scan_tiles) {
     // the scan has consumed its per-tile totals: leave them zero for the binning kernels of the next sort
     for (int k = blockIdx.x * BLK + threadIdx.x; k < scan_tiles; k += gridDim.x * BLK) block_sums[k] = 0u;
     for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {      // small grid: see k_key_hist
@@ -653,6 +654,17 @@ __global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, 
         id[dst] = __float_as_uint(q.z);
         skey[dst] = key;        // sorted keys: tile records, and the sort cell of a particle between rebuilds
     }
+}
+
+__global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, const float2 *__restrict__ velk,
+                                                 const uint32_t *__restrict__ slot,
+                                                 const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
+                                                 float2 *__restrict__ pos_ref, float2 *__restrict__ vel,
+                                                 uint32_t *__restrict__ id, uint32_t *__restrict__ skey,
+                                                 const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild,
+                                                 uint32_t *__restrict__ block_sums, int scan_tiles) {
+    if (*rebuild == 0u) return;
+    reorder_body(pk, velk, slot, cell_start, pos, pos_ref, vel, id, skey, (int)dn[0], block_sums, scan_tiles);
 }
 
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap) {

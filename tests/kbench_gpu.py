@@ -37,5 +37,23 @@ for _ in range(10):
     for k, v in kt.items():
         acc[k] = acc.get(k, 0.0) + v / 10
 print("rebuild every step:", {k: round(v * 1e3, 1) for k, v in acc.items() if k not in ("rebuilds_per_step",)}, "rebuilds/step", acc["rebuilds_per_step"])
+# the list build alone, back to back on the live sort (SPH_ABLATE_BUILD: 1 = no walk, 2 = no staging, 4 = lists not
+# written, 8 = stop after the runs);
+# whatever it leaves is replaced by the rebuild of the next step
+for abl in (("0", "1", "2", "3", "8", "0") if sph.LIB_HIP == ablate_lib else ("0",)):
+    os.environ["SPH_ABLATE_BUILD"] = abl
+    print("build_list SPH_ABLATE_BUILD=%s : %.2f us" % (abl, ctx.time_kernel("build_list", 20) * 1e3))
+if sph.LIB_HIP == ablate_lib:      # clock stamps of the phases of a few tiles (printed by the kernel)
+    os.environ["SPH_ABLATE_BUILD"] = "64"
+    ctx.time_kernel("build_list", 1)
+    ctx.sync()
+    ctx.set_rebuild_launches(True)   # ... and of the barriers of a one-launch rebuild (drops the captured graphs)
+    ctx.step(2)
+    ctx.sync()
+    ctx.request_rebuild()
+    ctx.step(1)
+    ctx.sync()
+os.environ.pop("SPH_ABLATE_BUILD", None)
 ctx.step(1)
 ctx.sync()
+print("after:", ctx.rebuild_stats())

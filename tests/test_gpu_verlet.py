@@ -162,3 +162,25 @@ def test_coherent_motion_keeps_lists(sph, orc, oracle):
     assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-4
     assert checks >= 140                      # the block moved more than skin/2 within two steps ...
     assert r1 - r0 <= 40, (r0, r1)            # ... but it moved together: few rebuilds (absolute criterion: ~75)
+
+
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_rebuild_launch_modes(sph, orc, oracle, one_launch):
+    """The rebuild chain of a step as one kernel with grid barriers (the default of single-GPU contexts) or as one kernel
+    per phase (sph_set_rebuild_launches), with a rebuild in every step (skin 0): same trajectory (against the oracle),
+    lists equal to an exact walk, nothing on the direct path."""
+    prm, f, b, g = block_scene(sph, orc, 0.0)
+    box = tuple(g["box"])
+    ob = boundary_particles(orc, g["boundary_xy"], g["psi"])
+    of = oracle_block_300(oracle, orc, f, ob, box)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.set_rebuild_launches(one_launch)
+        r0, _ = ctx.rebuild_stats()
+        ctx.step(300, GX, GY)
+        ctx.sync()
+        got = ctx.read_particles()
+        r1, direct = ctx.rebuild_stats()
+        lists_vs_exact_walk(ctx, one_launch)
+    assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-4
+    assert np.max(np.abs(got["rho"] - of["rho"]) / of["rho"]) <= 1e-3
+    assert r1 - r0 == 300 and direct == 0, (r0, r1, direct)
