@@ -280,43 +280,50 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
         key_hist_body<false>(c, pos, id, vsrc, cs, velk, pk, slot, count, dirty, flags, dn, nullptr, nullptr, chunk, block_sums);
 }
 
-// the pair part of criterion (1): one thread per box group, against every group k_build_list listed for it
+// the pair part of criterion (1): every box group against every group k_build_list listed for it, eight threads per group
+// (one per column range, three idle: the loads of a group are a chain of dependent latencies when one thread does them all)
+constexpr int CHECK_LANES = 8;
+DEV void check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr, uint32_t *__restrict__ rebuild,
+                     const int w, const int k, const int own_lo, const int own_hi);
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                                                const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
                                                uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
                                                const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
-                                               uint32_t *__restrict__ send_r) {
+                                               uint32_t *__restrict__ send_r, int nw) {
     // slab mode: this is the first kernel of a step; it also clears the headers of the send buffers (count, kind) for
     // the pack that follows the reduction of the rebuild word
     if (send_l && blockIdx.x == 0 && threadIdx.x < 2 * HALO_HDR) (threadIdx.x < HALO_HDR ? send_l : send_r)[threadIdx.x & (HALO_HDR - 1)] = 0u;
     if (*check == 0u) return;
-    const int w = blockIdx.x * BLK + threadIdx.x;
-    if (w == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
     const int n = (int)dn[0];
     // the slots this rank integrates (single GPU: all of them)
     const int own_lo = c.ghost ? (int)cs[c.ghost * c.rows] : 0, own_hi = c.ghost ? (int)cs[(c.ghost + c.owned) * c.rows] : n;
+    // (a small grid striding over the groups: see k_key_hist)
+    for (int t = blockIdx.x * BLK + threadIdx.x; t < nw * CHECK_LANES; t += gridDim.x * BLK) check_group(c, wbox, wnbr, rebuild, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi);
+}
+DEV void check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr, uint32_t *__restrict__ rebuild,
+                     const int w, const int k, const int own_lo, const int own_hi) {
     if (w * BOXG >= own_hi || (w + 1) * BOXG <= own_lo) return;      // no owned particle in this group: no box
     const float4 b = wbox[w];
     const uint32_t *nb = wnbr + (size_t)w * WNBR_WORDS;
     bool meets_ghosts = false;
+    if (c.ghost) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const uint32_t first = nb[2 * k], last = nb[2 * k + 1];
-        if (first <= last) meets_ghosts |= (int)(first * BOXG) < own_lo || (int)((last + 1u) * BOXG) > own_hi;
+        for (int j = 0; j < 5; j++) {
+            const uint32_t first = nb[2 * j], last = nb[2 * j + 1];
+            if (first <= last) meets_ghosts |= (int)(first * BOXG) < own_lo || (int)((last + 1u) * BOXG) > own_hi;
+        }
     }
     bool bad = false;
     if (meets_ghosts) {
         const float mx = fmaxf(fabsf(b.x), fabsf(b.z)), my = fmaxf(fabsf(b.y), fabsf(b.w));
-        bad = !(fmaf(mx, mx, my * my) <= c.lim2);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const uint32_t first = nb[2 * k], last = nb[2 * k + 1];
-            for (uint32_t o = first; o <= last && o != 0xffffffffu; o++) {      // first > last: nobody in that column
-                const float4 q = wbox[o];
-                const float rx = fmaxf(b.z - q.x, q.z - b.x), ry = fmaxf(b.w - q.y, q.w - b.y);
-                bad |= !(fmaf(rx, rx, ry * ry) <= c.skin2);
-            }
+        bad = k == 0 && !(fmaf(mx, mx, my * my) <= c.lim2);
+    } else if (k < 5) {
+        const uint32_t first = nb[2 * k], last = nb[2 * k + 1];
+        for (uint32_t o = first; o <= last && o != 0xffffffffu; o++) {      // first > last: nobody in that column
+            const float4 q = wbox[o];
+            const float rx = fmaxf(b.z - q.x, q.z - b.x), ry = fmaxf(b.w - q.y, q.w - b.y);
+            bad |= !(fmaf(rx, rx, ry * ry) <= c.skin2);
         }
     }
     if (bad) *rebuild = 1u;
@@ -324,7 +331,8 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
 void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
     if (cap <= 0) return;
     const int nw = (cap + BOXG - 1) / BOXG;
-    hipLaunchKernelGGL(k_check, dim3((nw + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check, a.rebuild, a.flags, a.dn, a.send[0], a.send[1]);
+    hipLaunchKernelGGL(k_check, dim3(gated_grid((nw * CHECK_LANES + BLK - 1) / BLK)), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check,
+                       a.rebuild, a.flags, a.dn, a.send[0], a.send[1], nw);
 }
 
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc) {
