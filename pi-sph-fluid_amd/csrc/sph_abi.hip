@@ -48,6 +48,7 @@ struct sph_ctx {
     // that look-ahead (false after creation / upload / eval_accel / variant change: the next step then starts with
     // the stand-alone kick/drift kernel instead).  One captured graph per orientation of the two sets.
     bool primed = false;
+    bool p_stale = false;        // the density passes of a step do not store p: refresh_p() before use
     bool velt_stale = false;     // the fused force pass does not store the velocity between steps: refresh_velt() before use
     bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
@@ -149,6 +150,11 @@ size_t padded_items(const Consts &c) {
 bool fused(const sph_ctx *ctx) { return ctx->variant == 0; }
 
 // the velocity after the second half kick (:638-639): the fused step leaves it to be recomputed on demand
+// p from the stored rho, as the density pass of the last step computed it (and p / rho^2 with it: the same value again)
+void refresh_p(sph_ctx *ctx) {
+    if (ctx->p_stale) launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, false);
+    ctx->p_stale = false;
+}
 void refresh_velt(sph_ctx *ctx) {
     if (ctx->velt_stale) launch_refresh_velt(ctx->stream, ctx->c, ctx->a, ctx->cap);
     ctx->velt_stale = false;
@@ -173,7 +179,7 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
         launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     }
     if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
-    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true);
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, DENS_ALL, false);
     if (ev) (void)hipEventRecord(ev[SPH_K_FORCE_KICK], st);
     launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     if (ev) (void)hipEventRecord(ev[SPH_K_HALO], st);   // = end of step
@@ -252,6 +258,7 @@ int run_step(sph_ctx *ctx, hipEvent_t *ev) {
     }
     ctx->primed = fused(ctx);
     ctx->velt_stale = fused(ctx);
+    ctx->p_stale = true;
     ctx->stepped = true;
     hipGraphExec_t g = ev ? nullptr : step_graph(ctx);
     if (g) HIPCHK(ctx, hipGraphLaunch(g, st));
@@ -550,6 +557,7 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
             if (g) {
                 HIPCHK(ctx, hipGraphLaunch(g, ctx->stream));
                 ctx->velt_stale = true;
+                ctx->p_stale = true;
                 s += MULTI_STEPS;
                 continue;
             }
@@ -573,6 +581,7 @@ int sph_read_particles(sph_ctx *ctx, sph_particle *out) {
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_read");
     (void)hipSetDevice(ctx->device);
     refresh_velt(ctx);
+    refresh_p(ctx);
     launch_unsort_particles(ctx->stream, ctx->c, ctx->a, ctx->n, ctx->d_aos);
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_aos, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -754,6 +763,7 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     // the arrays are rewritten, back in through the new sort order afterwards
     launch_unsort_accel(st, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
     ctx->velt_stale = false;      // velt is rewritten below
+    ctx->p_stale = false;         // ... and so are rho and p
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_aos, fluid, (size_t)ctx->n * sizeof(sph_particle), hipMemcpyHostToDevice, st));
     launch_upload_state(st, ctx->a, ctx->n, ctx->d_aos);
     ctx->primed = false;
@@ -785,6 +795,7 @@ int sph_upload_accel(sph_ctx *ctx, const float *du_dt, const float *dv_dt) {
 int sph_eval_density(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
+    refresh_p(ctx);               // the stored p, while the rho it belongs to is still there
     launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO, ctx->variant, false);
     launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, true);   // keep p/rho^2 consistent with the new rho and the stored p
     HIPCHK(ctx, hipGetLastError());
@@ -795,6 +806,7 @@ int sph_eval_pressure(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
     launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, false);
+    ctx->p_stale = false;
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
@@ -914,7 +926,7 @@ int sph_slab_step_overlap(sph_ctx *ctx) {
     if (!ctx->slab || ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_step_overlap without sph_slab_step_pack");
     (void)hipSetDevice(ctx->device);
     // density of the tiles that stage no ghost particle (nothing on a rebuild step): independent of the incoming halo
-    launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_INTERIOR);
+    launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_INTERIOR, false);
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_overlapped = true;
     return SPH_OK;
@@ -930,9 +942,10 @@ int sph_slab_step_end(sph_ctx *ctx) {
     launch_reorder(st, ctx->c, ctx->a, ctx->cap);
     launch_canon(st, ctx->c, ctx->a);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
-    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, ctx->slab_overlapped ? DENS_REST : DENS_ALL);
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, ctx->slab_overlapped ? DENS_REST : DENS_ALL, false);
     launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     ctx->velt_stale = fused(ctx);
+    ctx->p_stale = true;
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_overlapped = false;
     ctx->slab_phase = 0;
@@ -1023,6 +1036,7 @@ int sph_slab_read(sph_ctx *ctx, sph_particle *out, uint32_t *ids, float *du_dt, 
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     refresh_velt(ctx);
+    refresh_p(ctx);
     launch_export_owned(st, ctx->c, ctx->a, ctx->cap, ctx->d_aos, ctx->d_ids, ctx->d_du, ctx->d_dv);
     uint32_t hdn[4] = {0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(hdn, ctx->a.dn, sizeof hdn, hipMemcpyDeviceToHost, st));

@@ -179,8 +179,10 @@ enum { DENS_RHO = 0, DENS_RHO_EOS = 1 };
 // of it have served the request).  pass (slab mode: overlap with the halo exchange): DENS_ALL; DENS_INTERIOR = only the
 // tiles that stage no ghost, and nothing at all on a rebuild step; DENS_REST = what DENS_INTERIOR left out.
 enum { DENS_ALL = 0, DENS_INTERIOR = 1, DENS_REST = 2 };
+// store_p = false (the passes of a step): p itself is not written (4 bytes per particle that only a read-back looks at;
+// p / rho^2 is); the caller marks it stale and launch_eos restores it from rho, with the same arithmetic, on demand.
 void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild,
-                    int pass = DENS_ALL);
+                    int pass = DENS_ALL, bool store_p = true);
 // what the force pass writes besides a: nothing / velt (second half kick) / velt + the next step's kick 1/2 + drift
 // into pos2, vel2 + the next step's rebuild request
 enum { FORCE_EVAL = 0, FORCE_KICK = 1, FORCE_KICK_DRIFT = 2 };

@@ -856,9 +856,9 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
 namespace sph {
 
 void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild,
-                    int pass) {
+                    int pass, bool store_p) {
     if (cap <= 0) return;
-    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild, pass); return; }
+    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild, pass, store_p); return; }
     if (pass == DENS_INTERIOR) return;      // the direct variant is not split: everything in the final pass
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
     uint32_t *rb = consume_rebuild ? a.rebuild : nullptr;
