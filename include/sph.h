@@ -193,8 +193,10 @@ int  sph_set_variant(sph_ctx *ctx, int variant);
  * that rebuild nothing pay for one empty launch instead of four.  It needs the device to itself: if another process
  * keeps compute units busy with a kernel that does not end, a barrier gives up after a few seconds and the next call
  * that checks the flags returns SPH_E_STATE.  one_launch = 0: one kernel per phase (always the case for slab
- * contexts, which may share a device).  Results are the same either way. */
+ * contexts, which may share a device, and for a context that finds another context of the same process on its device
+ * when it steps).  Results are the same either way. */
 int  sph_set_rebuild_launches(sph_ctx *ctx, int one_launch);
+int  sph_get_rebuild_launches(const sph_ctx *ctx);      /* 1: one launch, 0: one kernel per phase (as of the last step) */
 
 /* ---- multi-GPU: x-slab domain decomposition, one process per GPU ----
  * The reference has no distributed path; this is the sharding of its particle loops (:272, :311) by cell column.

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "sph_create", "sph_destroy", "sph_last_error", "sph_step", "sph_sync",
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
-    "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_rebuild_stats", "sph_check_stats",
+    "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_get_rebuild_launches", "sph_rebuild_stats", "sph_check_stats",
     "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
     "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
     "sph_render_metaballs",
@@ -133,6 +133,7 @@ def hip_lib():
         L.sph_device_cell.restype = cf
         L.sph_request_rebuild.argtypes = [vp]
         L.sph_set_rebuild_launches.argtypes = [vp, C.c_int]
+        L.sph_get_rebuild_launches.argtypes = [vp]
         L.sph_rebuild_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.sph_check_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.sph_upload_state.argtypes = [vp, vp]
@@ -396,6 +397,10 @@ class Context:
     def set_rebuild_launches(self, one_launch):
         """True: the rebuild chain of a step is one kernel with grid barriers (default of single-GPU contexts)"""
         self._chk(self.L.sph_set_rebuild_launches(self.h, 1 if one_launch else 0))
+
+    def rebuild_launches(self):
+        """True: the last step ran its rebuild chain as one launch"""
+        return self.L.sph_get_rebuild_launches(self.h) == 1
 
     def request_rebuild(self):
         """the next step rebuilds the neighbour structure whatever the displacement criterion says"""

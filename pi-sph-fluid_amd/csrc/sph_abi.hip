@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <atomic>
 
 #include "sph.h"
 #include "sph_internal.h"
@@ -56,12 +57,20 @@ struct sph_ctx {
     hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
+    bool counted = false;        // this context is in g_live_contexts
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
     long long oob_total = 0, nan_total = 0;
     std::string err;
 };
 
 namespace {
+
+// Contexts of this process per device.  k_rebuild needs all its workgroups resident at once; two of them running
+// concurrently (two contexts stepped from one host thread, each on its own stream) could each hold half the device and
+// wait for the other half: a context that finds company on its device goes back to one kernel per phase.
+constexpr int MAX_DEVICES = 64;
+std::atomic<int> g_live_contexts[MAX_DEVICES];
+bool device_shared(const sph_ctx *ctx);
 
 int fail(sph_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
     if (ctx) {
@@ -148,6 +157,10 @@ size_t padded_items(const Consts &c) {
 }
 
 bool fused(const sph_ctx *ctx) { return ctx->variant == 0; }
+
+bool device_shared(const sph_ctx *ctx) {
+    return ctx->device >= 0 && ctx->device < MAX_DEVICES && g_live_contexts[ctx->device].load(std::memory_order_relaxed) > 1;
+}
 
 // the velocity after the second half kick (:638-639): the fused step leaves it to be recomputed on demand
 // p from the stored rho, as the density pass of the last step computed it (and p / rho^2 with it: the same value again)
@@ -345,6 +358,7 @@ void sph_destroy(sph_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->counted) g_live_contexts[ctx->device].fetch_sub(1);
     drop_graph(ctx);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
@@ -429,6 +443,10 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         ctx->own_halo = true;
     }
 #undef ALLOC
+    if (ctx->device < MAX_DEVICES) {
+        g_live_contexts[ctx->device].fetch_add(1);
+        ctx->counted = true;
+    }
     if (!slab) ctx->rebuild_wgs = rebuild_grid(ctx->device, ctx->cap);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
@@ -549,6 +567,11 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
     if (!ctx->stream) return fail(ctx, SPH_E_STATE, "context not initialised");
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_step_begin / exchange / sph_slab_step_end");
     (void)hipSetDevice(ctx->device);
+    if (ctx->rebuild_wgs > 0 && device_shared(ctx)) {      // another context of this process on the device: see g_live_contexts
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        drop_graph(ctx);
+        ctx->rebuild_wgs = 0;
+    }
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     int s = 0;
     while (s < nsteps) {
@@ -721,6 +744,8 @@ int sph_set_rebuild_launches(sph_ctx *ctx, int one_launch) {
     if (one_launch && ctx->rebuild_wgs <= 0) return fail(ctx, SPH_E_HIP, "occupancy query for the one-launch rebuild failed");
     return SPH_OK;
 }
+
+int sph_get_rebuild_launches(const sph_ctx *ctx) { return ctx ? (ctx->rebuild_wgs > 0 ? 1 : 0) : SPH_E_ARG; }
 
 int sph_set_variant(sph_ctx *ctx, int variant) {
     if (!ctx || variant < 0 || variant > 1) return SPH_E_ARG;

@@ -180,7 +180,26 @@ def test_rebuild_launch_modes(sph, orc, oracle, one_launch):
         ctx.sync()
         got = ctx.read_particles()
         r1, direct = ctx.rebuild_stats()
+        assert ctx.rebuild_launches() == one_launch      # (a second live context on the device would have switched it off)
         lists_vs_exact_walk(ctx, one_launch)
     assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-4
     assert np.max(np.abs(got["rho"] - of["rho"]) / of["rho"]) <= 1e-3
     assert r1 - r0 == 300 and direct == 0, (r0, r1, direct)
+
+
+def test_two_contexts_on_one_device_use_separate_launches(sph, orc):
+    """Two one-launch rebuilds running at once could each hold half the device and wait for the other half: a context
+    that finds another context of the process on its device steps with one kernel per phase."""
+    prm, f, b, g = block_scene(sph, orc, 0.0)
+    with sph.Context(prm, f, b, GX, GY) as c1:
+        c1.step(8, GX, GY)
+        assert c1.rebuild_launches()
+        with sph.Context(prm, f, b, GX, GY) as c2:
+            for _ in range(4):
+                c1.step(8, GX, GY)
+                c2.step(8, GX, GY)
+            c1.sync()
+            c2.sync()
+            assert not c1.rebuild_launches() and not c2.rebuild_launches()
+            a, b2 = c1.read_particles(), c2.read_particles()
+            assert np.all(np.isfinite(a["x"])) and np.all(np.isfinite(b2["x"]))
