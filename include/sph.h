@@ -192,9 +192,10 @@ int  sph_set_variant(sph_ctx *ctx, int variant);
  * ONE kernel with grid barriers between the phases, sized to what the device holds at once, so that the many steps
  * that rebuild nothing pay for one empty launch instead of four.  It needs the device to itself: if another process
  * keeps compute units busy with a kernel that does not end, a barrier gives up after a few seconds and the next call
- * that checks the flags returns SPH_E_STATE.  one_launch = 0: one kernel per phase (always the case for slab
- * contexts, which may share a device, and for a context that finds another context of the same process on its device
- * when it steps).  Results are the same either way. */
+ * that checks the flags returns SPH_E_STATE.  one_launch = 0: one kernel per phase (what a context does anyway while
+ * another context of the same process lives on its device: several slabs on one GPU, A/B comparisons).  Slab contexts
+ * do the same with what follows their halo exchange (ghost update / ingest, scan, scatter, canonical order, lists).
+ * Results are the same either way. */
 int  sph_set_rebuild_launches(sph_ctx *ctx, int one_launch);
 int  sph_get_rebuild_launches(const sph_ctx *ctx);      /* 1: one launch, 0: one kernel per phase (as of the last step) */
 

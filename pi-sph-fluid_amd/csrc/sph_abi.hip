@@ -447,7 +447,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         g_live_contexts[ctx->device].fetch_add(1);
         ctx->counted = true;
     }
-    if (!slab) ctx->rebuild_wgs = rebuild_grid(ctx->device, ctx->cap);
+    ctx->rebuild_wgs = rebuild_grid(ctx->device, ctx->cap);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
@@ -736,7 +736,6 @@ size_t sph_device_bytes(const sph_ctx *ctx) { return ctx ? ctx->bytes : 0; }
 
 int sph_set_rebuild_launches(sph_ctx *ctx, int one_launch) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
-    if (ctx->slab && one_launch) return fail(ctx, SPH_E_STATE, "slab contexts rebuild with one kernel per phase");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     drop_graph(ctx);
@@ -916,7 +915,6 @@ int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
     if (!ctx->slab || ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_step_begin: not a slab context or already mid-step");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    launch_set_gravity(st, ctx->a, gx, gy);
     // kick 1/2 + drift of the owned range: done by the previous step's force pass (swap the sets; the ghost entries of
     // the swapped-in set are refreshed by this step's halo exchange) or by the stand-alone kernel; either has raised
     // the rebuild word if the lists may be stale
@@ -928,7 +926,8 @@ int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
         launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, true);
     }
     ctx->primed = fused(ctx);
-    launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2 somewhere: compare the boxes; may raise the rebuild word
+    const float gravity[2] = {gx, gy};
+    launch_check(st, ctx->c, ctx->a, ctx->cap, gravity);      // beyond skin/2 somewhere: compare the boxes; may raise the rebuild word
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_phase = 1;
     return SPH_OK;
@@ -962,11 +961,15 @@ int sph_slab_step_end(sph_ctx *ctx) {
     if (!ctx->slab || ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_pack");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    launch_halo_in(st, ctx->c, ctx->a, ctx->cap);               // rebuild step: ingest (then the next four); else ghost update
-    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
-    launch_reorder(st, ctx->c, ctx->a, ctx->cap);
-    launch_canon(st, ctx->c, ctx->a);
-    launch_build_list(st, ctx->c, ctx->a, ctx->cap);
+    if (ctx->rebuild_wgs > 0 && !device_shared(ctx)) {      // alone on the device: one launch (see g_live_contexts)
+        launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs);
+    } else {
+        launch_halo_in(st, ctx->c, ctx->a, ctx->cap);               // rebuild step: ingest (then the next four); else ghost update
+        launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
+        launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+        launch_canon(st, ctx->c, ctx->a);
+        launch_build_list(st, ctx->c, ctx->a, ctx->cap);
+    }
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, ctx->slab_overlapped ? DENS_REST : DENS_ALL, false);
     launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     ctx->velt_stale = fused(ctx);

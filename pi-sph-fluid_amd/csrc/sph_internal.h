@@ -148,6 +148,9 @@ void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
 // between the phases: `grid` workgroups, all resident at once (rebuild_grid).  A no-op unless the rebuild word is set.
 int rebuild_grid(int device, int cap);
 void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid);
+// slab mode, what follows the halo exchange, as one launch: ghost update, or (rebuild step) ingest -> scan -> scatter ->
+// canonical order of the interface cells -> tile records + lists
+void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid);
 // raise the rebuild request: the next step rebuilds the neighbour structure
 void launch_request_rebuild(hipStream_t st, const Arrays &a);
 // first half kick + drift in place (:615-624; slab mode: the owned range); requests a rebuild when the lists may be stale
@@ -166,7 +169,8 @@ void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int c
                          float *du, float *dv);
 // single GPU: if the check word is set, compare the displacement boxes of neighbouring waves; raise the rebuild word
 // when two of them moved more than the skin relative to each other
-void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// gravity != nullptr: (gx, gy) of this step, written to the device by the same launch (slab step)
+void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity = nullptr);
 // rebuild kernels (no-ops unless flags[FLAG_REBUILD]): scan, scatter, tile records + neighbour lists
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
                  uint32_t *block_sums, const uint32_t *rebuild, bool reduce);

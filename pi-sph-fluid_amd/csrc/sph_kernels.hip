@@ -289,7 +289,9 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
                                                const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
                                                uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
                                                const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
-                                               uint32_t *__restrict__ send_r, int nw) {
+                                               uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy) {
+    // (slab mode: the gravity of this step rides along instead of taking a launch of its own)
+    if (grav && blockIdx.x == 0 && threadIdx.x == 0) *grav = make_float2(gx, gy);
     // slab mode: this is the first kernel of a step; it also clears the headers of the send buffers (count, kind) for
     // the pack that follows the reduction of the rebuild word
     if (send_l && blockIdx.x == 0 && threadIdx.x < 2 * HALO_HDR) (threadIdx.x < HALO_HDR ? send_l : send_r)[threadIdx.x & (HALO_HDR - 1)] = 0u;
@@ -328,11 +330,12 @@ DEV void check_group(const Consts &c, const float4 *__restrict__ wbox, const uin
     }
     if (bad) *rebuild = 1u;
 }
-void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity) {
     if (cap <= 0) return;
     const int nw = (cap + BOXG - 1) / BOXG;
     hipLaunchKernelGGL(k_check, dim3(gated_grid((nw * CHECK_LANES + BLK - 1) / BLK)), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check,
-                       a.rebuild, a.flags, a.dn, a.send[0], a.send[1], nw);
+                       a.rebuild, a.flags, a.dn, a.send[0], a.send[1], nw, gravity ? a.grav : nullptr, gravity ? gravity[0] : 0.0f,
+                       gravity ? gravity[1] : 0.0f);
 }
 
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc) {
@@ -391,12 +394,15 @@ __global__ __launch_bounds__(BLK) void k_halo_out(Consts c, const float2 *__rest
                                                   const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
                                                   uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r,
                                                   int part_blocks, int halo_blocks, uint32_t *__restrict__ block_sums) {
+    // (a small grid striding over the work: on most steps only the two update packs run; see k_key_hist)
     if (*rebuild != 0u) {
-        if ((int)blockIdx.x < part_blocks)
-            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r, (int)blockIdx.x, block_sums);
-    } else if ((int)blockIdx.x < 2 * halo_blocks) {
-        const int side = (int)blockIdx.x / halo_blocks;
-        pack_update_body(c, side, ((int)blockIdx.x - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, send_l, send_r);
+        for (int vb = (int)blockIdx.x; vb < part_blocks; vb += (int)gridDim.x)
+            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r, vb, block_sums);
+    } else {
+        for (int vb = (int)blockIdx.x; vb < 2 * halo_blocks; vb += (int)gridDim.x) {
+            const int side = vb / halo_blocks;
+            pack_update_body(c, side, (vb - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, send_l, send_r);
+        }
     }
 }
 
@@ -404,7 +410,7 @@ void launch_halo_out(hipStream_t st, const Consts &c, const Arrays &a, int cap) 
     if (cap <= 0) return;
     const int part_blocks = (cap + BLK - 1) / BLK, halo_blocks = (c.halo_cap + BLK - 1) / BLK;
     const int grid = part_blocks > 2 * halo_blocks ? part_blocks : 2 * halo_blocks;
-    hipLaunchKernelGGL(k_halo_out, dim3(grid), dim3(BLK), 0, st, c, a.pos, a.id, a.vel, a.cell_start, a.velk, a.pk, a.slot,
+    hipLaunchKernelGGL(k_halo_out, dim3(gated_grid(grid)), dim3(BLK), 0, st, c, a.pos, a.id, a.vel, a.cell_start, a.velk, a.pk, a.slot,
                        a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1], part_blocks, halo_blocks, a.block_sums);
 }
 
@@ -412,12 +418,9 @@ void launch_halo_out(hipStream_t st, const Consts &c, const Arrays &a, int cap) 
 // on each side) into ascending particle-id order.  Both neighbours hold the same particles in those cells, so after
 // this their sequences agree and updates can be exchanged as contiguous ranges.  One thread per cell, selection sort
 // in place (a cell holds ~7 particles).
-__global__ __launch_bounds__(BLK) void k_canon(Consts c, float2 *__restrict__ pos, float2 *__restrict__ pos_ref,
-                                               float2 *__restrict__ vel, uint32_t *__restrict__ id,
-                                               const uint32_t *__restrict__ cs, const uint32_t *__restrict__ rebuild) {
-    if (*rebuild == 0u) return;
+DEV void canon_cell(const Consts &c, const int t, float2 *__restrict__ pos, float2 *__restrict__ pos_ref, float2 *__restrict__ vel,
+                    uint32_t *__restrict__ id, const uint32_t *__restrict__ cs) {
     const int span = (c.ghost + 2) * c.rows;          // cells per side
-    const int t = blockIdx.x * BLK + threadIdx.x;
     if (t >= 2 * span) return;
     const bool right = t >= span;
     if (right ? !c.has_right : !c.has_left) return;
@@ -437,6 +440,12 @@ __global__ __launch_bounds__(BLK) void k_canon(Consts c, float2 *__restrict__ po
         }
     }
 }
+__global__ __launch_bounds__(BLK) void k_canon(Consts c, float2 *__restrict__ pos, float2 *__restrict__ pos_ref,
+                                               float2 *__restrict__ vel, uint32_t *__restrict__ id,
+                                               const uint32_t *__restrict__ cs, const uint32_t *__restrict__ rebuild) {
+    if (*rebuild == 0u) return;
+    canon_cell(c, blockIdx.x * BLK + threadIdx.x, pos, pos_ref, vel, id, cs);
+}
 void launch_canon(hipStream_t st, const Consts &c, const Arrays &a) {
     if (!(c.has_left || c.has_right)) return;
     const int work = 2 * (c.ghost + 2) * c.rows;
@@ -448,11 +457,11 @@ void launch_canon(hipStream_t st, const Consts &c, const Arrays &a) {
 DEV void ingest_body(const Consts &c, const uint32_t *__restrict__ recv_l, const uint32_t *__restrict__ recv_r,
                      float2 *__restrict__ velk, float4 *__restrict__ pk, uint32_t *__restrict__ slot,
                      uint32_t *__restrict__ count, uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
-                     uint32_t *__restrict__ dn, int stage_cap, uint32_t *__restrict__ block_sums) {
+                     uint32_t *__restrict__ dn, int stage_cap, uint32_t *__restrict__ block_sums, const int vblock) {
     const int n_own = (int)dn[1];
     const int nl = c.has_left ? min((int)recv_l[0], c.halo_cap) : 0;
     const int nr = c.has_right ? min((int)recv_r[0], c.halo_cap) : 0;
-    const int t = blockIdx.x * BLK + threadIdx.x;
+    const int t = vblock * BLK + threadIdx.x;
     if (t == 0) {
         int total = n_own + nl + nr;
         if (total > stage_cap) { atomicAdd(&flags[FLAG_CAPACITY], 1u); total = stage_cap; }
@@ -477,7 +486,7 @@ DEV void ingest_body(const Consts &c, const uint32_t *__restrict__ recv_l, const
             const uint32_t tk = (uint32_t)__shfl((int)tkey, lead, 64);
             const unsigned long long same = __ballot(mine && tkey == tk) & todo;
             if ((int)(threadIdx.x & 63) == lead)
-                atomicAdd(&block_sums[tk * SCAN_SPREAD + ((blockIdx.x * (BLK / 64) + (threadIdx.x >> 6)) & (SCAN_SPREAD - 1))],
+                atomicAdd(&block_sums[tk * SCAN_SPREAD + (((uint32_t)vblock * (BLK / 64) + (threadIdx.x >> 6)) & (SCAN_SPREAD - 1))],
                           (uint32_t)__builtin_popcountll(same));
             todo &= ~same;
         }
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(BLK) void k_halo_in(Consts c, const uint32_t *__res
                                                  uint32_t *__restrict__ block_sums) {
     if (blockIdx.x == 0 && threadIdx.x == 0) flags[FLAG_LATCH] = *rebuild;      // for the final density pass (DENS_REST)
     if (*rebuild != 0u) {
-        ingest_body(c, recv_l, recv_r, velk, pk, slot, count, dirty, flags, dn, stage_cap, block_sums);
+        ingest_body(c, recv_l, recv_r, velk, pk, slot, count, dirty, flags, dn, stage_cap, block_sums, (int)blockIdx.x);
     } else {
         const int side = (int)blockIdx.x / halo_blocks;
         unpack_update_body(c, side, ((int)blockIdx.x - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, recv_l, recv_r);

