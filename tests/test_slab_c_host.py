@@ -81,3 +81,17 @@ def test_c_host_tilt_run_and_rank_count_guard(sph):
     r = subprocess.run([HOST, "--ranks", str(ndev + 1), "--block", "400", "100", "60", "20", "--steps", "2", "--warmup", "1"],
                        capture_output=True, timeout=120)
     assert r.returncode != 0 and b"RCCL does not share a device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_two_ranks_over_rccl(sph):
+    """two ranks on two GPUs (skipped on a one-GPU box: RCCL does not share a device): the halo exchange and the reduction of
+    the rebuild word over RCCL; every particle owned exactly once at the end, rebuilds in step on both ranks."""
+    if sph.hip_lib().sph_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    r = subprocess.run([HOST, "--ranks", "2", "--block", "600", "150", "90", "20", "--steps", "300", "--warmup", "100"],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rec = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True
+    assert rec["ticks_per_s"] > 0 and 0 < rec["neighbour_rebuilds"] < 400
