@@ -190,9 +190,10 @@ size_t sph_device_bytes(const sph_ctx *ctx);
 int  sph_set_variant(sph_ctx *ctx, int variant);
 /* How a step launches its rebuild chain (binning, scan, scatter, lists): one_launch = 1 (default of single-GPU contexts):
  * ONE kernel with grid barriers between the phases, sized to what the device holds at once, so that the many steps
- * that rebuild nothing pay for one empty launch instead of four.  It needs the device to itself: if another process
- * keeps compute units busy with a kernel that does not end, a barrier gives up after a few seconds and the next call
- * that checks the flags returns SPH_E_STATE.  one_launch = 0: one kernel per phase (what a context does anyway while
+ * that rebuild nothing pay for one empty launch instead of four.  It needs the device to itself: sph_create tries its
+ * barriers once and falls back to one kernel per phase where they do not complete (compute units masked off or held
+ * by another process); should that happen later, a barrier gives up after a few seconds and the next call that checks
+ * the flags returns SPH_E_STATE.  one_launch = 0: one kernel per phase (what a context does anyway while
  * another context of the same process lives on its device: several slabs on one GPU, A/B comparisons).  Slab contexts
  * do the same with what follows their halo exchange (ghost update / ingest, scan, scatter, canonical order, lists).
  * Results are the same either way. */

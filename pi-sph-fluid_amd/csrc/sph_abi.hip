@@ -322,6 +322,22 @@ int check_flags(sph_ctx *ctx) {
     return SPH_OK;
 }
 
+// The one-launch rebuild needs all its workgroups resident at once.  Try its barriers once, now: where they do not
+// complete (compute units masked off or held by somebody else), this context rebuilds with one kernel per phase.
+int selftest_one_launch(sph_ctx *ctx) {
+    if (ctx->rebuild_wgs <= 0 || device_shared(ctx)) return SPH_OK;      // (in company the context does not use it: sph_step)
+    hipStream_t st = ctx->stream;
+    launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, true);
+    uint32_t timed_out = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&timed_out, ctx->a.flags + FLAG_BAR_TIMEOUT, sizeof timed_out, hipMemcpyDeviceToHost, st));
+    // (the next launch waits for the same barrier values again: the rebuild count has not moved)
+    HIPCHK(ctx, hipMemsetAsync(ctx->a.gbar, 0, sizeof(uint32_t) * (size_t)GBAR_WORDS * GBAR_STRIDE, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_BAR_TIMEOUT, 0, sizeof(uint32_t), st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (timed_out) ctx->rebuild_wgs = 0;
+    return SPH_OK;
+}
+
 int select_device(sph_ctx *ctx, int device) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -501,7 +517,9 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     launch_force(st, ctx->c, a, ctx->cap, FORCE_EVAL, ctx->variant);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(st));   // also keeps hb / fluid alive until the copies are done
-    return check_flags(ctx);
+    rc = check_flags(ctx);
+    if (rc) return rc;
+    return selftest_one_launch(ctx);
 }
 
 }  // namespace
@@ -741,6 +759,11 @@ int sph_set_rebuild_launches(sph_ctx *ctx, int one_launch) {
     drop_graph(ctx);
     ctx->rebuild_wgs = one_launch ? rebuild_grid(ctx->device, ctx->cap) : 0;
     if (one_launch && ctx->rebuild_wgs <= 0) return fail(ctx, SPH_E_HIP, "occupancy query for the one-launch rebuild failed");
+    if (one_launch) {
+        int rc = selftest_one_launch(ctx);
+        if (rc) return rc;
+        if (ctx->rebuild_wgs <= 0) return fail(ctx, SPH_E_STATE, "the one-launch rebuild's workgroups are not all resident on this device");
+    }
     return SPH_OK;
 }
 

@@ -147,7 +147,8 @@ void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
 // the whole rebuild chain of a step (binning, scan, scatter, tile records + lists) as ONE launch with grid barriers
 // between the phases: `grid` workgroups, all resident at once (rebuild_grid).  A no-op unless the rebuild word is set.
 int rebuild_grid(int device, int cap);
-void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid);
+// selftest: only the barriers (sph_create checks that they complete on this device before it relies on them)
+void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool selftest = false);
 // slab mode, what follows the halo exchange, as one launch: ghost update, or (rebuild step) ingest -> scan -> scatter ->
 // canonical order of the interface cells -> tile records + lists
 void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid);
