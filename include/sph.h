@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 3
+#define SPH_ABI_VERSION 4
 
 typedef enum sph_error {
     SPH_OK = 0,
@@ -62,6 +62,14 @@ typedef struct sph_params {
     float k2;     /* 0.2    artificial pressure reference q    :325 */
     float skin;   /* 0.15   Verlet skin of the neighbour structure as a fraction of 2H (no reference counterpart: the
                             reference rebuilds every step, :626 = skin 0).  Per context; see "neighbour-structure reuse" */
+    int deterministic;   /* 0 (default): the particles of a grid cell are kept in the order in which the binning atomics
+                            arrived, which differs from run to run (results agree to rounding: the summation order of a
+                            particle's neighbours follows it).  1: in particle-id order (one more pass per rebuild, < 1 % of
+                            a step): results are bit-identical from run to run (the reference is deterministic too: one
+                            fixed traversal order), and the same bits on one GPU and in any number of slabs
+                            as long as both rebuild in the same steps (the order follows the cells at the last rebuild):
+                            always with skin = 0; with a skin, a slab may rebuild a step earlier than a single context
+                            would (waves next to ghost particles use the absolute criterion) */
 } sph_params;
 
 typedef struct sph_ctx sph_ctx;

@@ -60,7 +60,7 @@ class Params(C.Structure):
                 ("g", C.c_float), ("dt", C.c_float), ("vol", C.c_float),
                 ("x_min", C.c_float), ("x_max", C.c_float), ("y_min", C.c_float), ("y_max", C.c_float),
                 ("alpha", C.c_float), ("eps", C.c_float), ("k1", C.c_float), ("k2", C.c_float),
-                ("skin", C.c_float)]
+                ("skin", C.c_float), ("deterministic", C.c_int)]
 
 
 class KernelTimes(C.Structure):
@@ -198,7 +198,7 @@ def host_lib():
     return _host
 
 
-def default_params(box=None, skin=None):
+def default_params(box=None, skin=None, deterministic=False):
     """reference defaults (:11-20); box = (x_min, x_max, y_min, y_max); skin = Verlet skin as a fraction of 2H
     (None: the library default; 0: rebuild the neighbour structure every step like the reference, :626)."""
     p = Params()
@@ -207,6 +207,7 @@ def default_params(box=None, skin=None):
         p.x_min, p.x_max, p.y_min, p.y_max = [float(v) for v in box]
     if skin is not None:
         p.skin = float(skin)
+    p.deterministic = 1 if deterministic else 0
     return p
 
 

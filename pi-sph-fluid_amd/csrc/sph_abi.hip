@@ -41,6 +41,7 @@ struct sph_ctx {
     float2 *d_bpos_in = nullptr, *d_bvel_in = nullptr;   // nb : wall particles as given (original order), staging of the wall bins
     uint32_t *d_bkey = nullptr;       // nb : their cells
     float *d_bpsi0 = nullptr;         // nb : pseudo-mass in original order (kept across sph_update_boundary)
+    uint32_t *d_bcell_ids = nullptr;   // wall particles: the members of every cell in slot order (deterministic order inside a cell)
     unsigned char *d_bits = nullptr;  // metaball frame, 1024 bytes of SSD1306 page format
     std::vector<void *> allocs;
     size_t bytes = 0;
@@ -58,6 +59,7 @@ struct sph_ctx {
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
     bool counted = false;        // this context is in g_live_contexts
+    bool deterministic = false;  // particles of a cell in id order (sph_set_deterministic)
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
     long long oob_total = 0, nan_total = 0;
     std::string err;
@@ -181,13 +183,13 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
     if (!ctx->slab) launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2: do neighbouring waves still move together?
     if (ctx->rebuild_wgs > 0 && !ev) {
-        launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs);
+        launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic);
     } else {       // (the profiled step, and contexts that may share their device: one kernel per phase)
         launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
         if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
         launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
         if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
-        launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+        launch_reorder(st, ctx->c, ctx->a, ctx->cap, ctx->deterministic);
         if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
         launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     }
@@ -285,7 +287,7 @@ int resort_state(sph_ctx *ctx) {
     launch_set_rebuild(st, ctx->a, true);
     launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.velt);
     launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
-    launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+    launch_reorder(st, ctx->c, ctx->a, ctx->cap, ctx->deterministic);
     if (ctx->slab) launch_canon(st, ctx->c, ctx->a);
     launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     launch_set_rebuild(st, ctx->a, false);
@@ -398,6 +400,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
                  const SlabSpec *slab) {
     ctx->prm = *prm;
     if (make_consts(*prm, ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "invalid parameters (skin must be within [0, 1]) or grid too large");
+    if (prm->deterministic != 0 && prm->deterministic != 1) return fail(ctx, SPH_E_ARG, "sph_params.deterministic must be 0 or 1");
+    ctx->deterministic = prm->deterministic == 1;
     ctx->skin = ctx->c.cell - 2 * prm->h;
     if (slab) {
         Consts &c = ctx->c;
@@ -451,7 +455,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(ctx->d_ids, n);
     float2 *&bpos_in = ctx->d_bpos_in, *&bvel_in = ctx->d_bvel_in;
     uint32_t *&bkey = ctx->d_bkey;
-    ALLOC(bpos_in, nb); ALLOC(bvel_in, nb); ALLOC(bkey, nb); ALLOC(ctx->d_bpsi0, nb);
+    ALLOC(bpos_in, nb); ALLOC(bvel_in, nb); ALLOC(bkey, nb); ALLOC(ctx->d_bpsi0, nb); ALLOC(ctx->d_bcell_ids, nb);
     a.send[0] = a.send[1] = a.recv[0] = a.recv[1] = nullptr;
     if (slab) {
         ctx->halo_bytes = sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * slab->halo_cap);
@@ -496,7 +500,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     launch_set_rebuild(st, a, true);        // the scan is a rebuild kernel
     launch_boundary_key(st, ctx->c, bpos_in, bkey, a.slot, a.count, a.dirty, a.flags, n_boundary);
     launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild, true);
-    launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary, bvel_in, a.bvel);
+    launch_boundary_reorder(st, bpos_in, bkey, a.slot, a.bcell_start, a.bpos, a.bid, n_boundary, bvel_in, a.bvel, ctx->d_bcell_ids);
     launch_boundary_near(st, ctx->c, a);
     if (psi_given) {
         // psi was computed on the full wall set (a slab sees only its part of the walls): scatter it to bin order
@@ -668,7 +672,7 @@ int sph_update_boundary(sph_ctx *ctx, const sph_particle *boundary) {
     launch_set_rebuild(st, a, true);
     launch_boundary_key(st, ctx->c, ctx->d_bpos_in, ctx->d_bkey, a.slot, a.count, a.dirty, a.flags, ctx->nb);
     launch_scan(st, ctx->c, a.count, a.dirty, a.bcell_start, a.block_sums, a.rebuild, true);
-    launch_boundary_reorder(st, ctx->d_bpos_in, ctx->d_bkey, a.slot, a.bcell_start, a.bpos, a.bid, ctx->nb, ctx->d_bvel_in, a.bvel);
+    launch_boundary_reorder(st, ctx->d_bpos_in, ctx->d_bkey, a.slot, a.bcell_start, a.bpos, a.bid, ctx->nb, ctx->d_bvel_in, a.bvel, ctx->d_bcell_ids);
     launch_boundary_gather_psi(st, a, ctx->d_bpsi0, ctx->nb);
     launch_boundary_near(st, ctx->c, a);
     // the rebuild word stays raised: the tile records count the wall particles in reach of each tile, so the next step
@@ -985,11 +989,11 @@ int sph_slab_step_end(sph_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     if (ctx->rebuild_wgs > 0 && !device_shared(ctx)) {      // alone on the device: one launch (see g_live_contexts)
-        launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs);
+        launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic);
     } else {
         launch_halo_in(st, ctx->c, ctx->a, ctx->cap);               // rebuild step: ingest (then the next four); else ghost update
         launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
-        launch_reorder(st, ctx->c, ctx->a, ctx->cap);
+        launch_reorder(st, ctx->c, ctx->a, ctx->cap, ctx->deterministic);
         launch_canon(st, ctx->c, ctx->a);
         launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     }

@@ -148,10 +148,10 @@ void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
 // between the phases: `grid` workgroups, all resident at once (rebuild_grid).  A no-op unless the rebuild word is set.
 int rebuild_grid(int device, int cap);
 // selftest: only the barriers (sph_create checks that they complete on this device before it relies on them)
-void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool selftest = false);
+void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool selftest = false, bool deterministic = false);
 // slab mode, what follows the halo exchange, as one launch: ghost update, or (rebuild step) ingest -> scan -> scatter ->
 // canonical order of the interface cells -> tile records + lists
-void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid);
+void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool deterministic = false);
 // raise the rebuild request: the next step rebuilds the neighbour structure
 void launch_request_rebuild(hipStream_t st, const Arrays &a);
 // first half kick + drift in place (:615-624; slab mode: the owned range); requests a rebuild when the lists may be stale
@@ -175,7 +175,9 @@ void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, con
 // rebuild kernels (no-ops unless flags[FLAG_REBUILD]): scan, scatter, tile records + neighbour lists
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
                  uint32_t *block_sums, const uint32_t *rebuild, bool reduce);
-void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap);
+// deterministic: the order of the particles inside a cell is by particle id (one more gated launch: the members of every
+// cell are written out first) instead of the order in which the binning atomics arrived
+void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool deterministic = false);
 void launch_build_list(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 // variant: 0 = LDS-tiled neighbour lists (default), 1 = direct global loads over the cell ranges (A/B measurements)
 // mode: what the density pass writes
@@ -198,7 +200,7 @@ void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in,
                          uint32_t *count, uint32_t *dirty, uint32_t *flags, int nb);
 void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
                              const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb, const float2 *bvel_in,
-                             float2 *bvel);
+                             float2 *bvel, uint32_t *cell_ids_tmp);
 void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb);
 // per-cell flag "walls within reach" from the wall bins (init; again whenever the walls are re-binned)
 void launch_boundary_near(hipStream_t st, const Consts &c, const Arrays &a);

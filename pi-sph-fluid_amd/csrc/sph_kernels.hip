@@ -655,16 +655,40 @@ void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dir
 
 // ------------------------------------------------------------------------------------------
 // P4: scatter to cell order (rebuild kernel).  The sorted positions are the reference positions of the new lists.
+// Deterministic order (optional): the members of every cell in slot order, so that the scatter can rank a particle by
+// its id among them.  The slots are handed out in the order the binning atomics arrive, which differs from run to run.
+DEV void cell_ids_body(const float4 *__restrict__ pk, const uint32_t *__restrict__ slot, const uint32_t *__restrict__ cell_start,
+                       uint32_t *__restrict__ cell_ids, const int n) {
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        const float4 q = pk[i];
+        cell_ids[cell_start[__float_as_uint(q.w)] + slot[i]] = __float_as_uint(q.z);
+    }
+}
+__global__ __launch_bounds__(BLK) void k_cell_ids(const float4 *__restrict__ pk, const uint32_t *__restrict__ slot,
+                                                  const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cell_ids,
+                                                  const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild) {
+    if (*rebuild == 0u) return;
+    cell_ids_body(pk, slot, cell_start, cell_ids, (int)dn[0]);
+}
+
+// cell_ids != nullptr: deterministic order inside a cell (by particle id)
 DEV void reorder_body(const float4 *__restrict__ pk, const float2 *__restrict__ velk, const uint32_t *__restrict__ slot,
                       const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos, float2 *__restrict__ pos_ref,
                       float2 *__restrict__ vel, uint32_t *__restrict__ id, uint32_t *__restrict__ skey, const int n,
-                      uint32_t *__restrict__ block_sums, const int scan_tiles) {
+                      uint32_t *__restrict__ block_sums, const int scan_tiles, const uint32_t *__restrict__ cell_ids) {
     // the scan has consumed its per-tile totals: leave them zero for the binning kernels of the next sort
     for (int k = blockIdx.x * BLK + threadIdx.x; k < scan_tiles; k += gridDim.x * BLK) block_sums[k] = 0u;
     for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {      // small grid: see k_key_hist
         float4 q = pk[i];
         const uint32_t key = __float_as_uint(q.w);
-        uint32_t dst = cell_start[key] + slot[i];
+        uint32_t dst;
+        if (cell_ids) {
+            const uint32_t beg = cell_start[key], end = cell_start[key + 1], mine = __float_as_uint(q.z);
+            dst = beg;
+            for (uint32_t j = beg; j < end; j++) dst += cell_ids[j] < mine ? 1u : 0u;
+        } else {
+            dst = cell_start[key] + slot[i];
+        }
         pos[dst] = make_float2(q.x, q.y);
         pos_ref[dst] = make_float2(q.x, q.y);
         vel[dst] = velk[i];
@@ -679,16 +703,20 @@ __global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, 
                                                  float2 *__restrict__ pos_ref, float2 *__restrict__ vel,
                                                  uint32_t *__restrict__ id, uint32_t *__restrict__ skey,
                                                  const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild,
-                                                 uint32_t *__restrict__ block_sums, int scan_tiles) {
+                                                 uint32_t *__restrict__ block_sums, int scan_tiles,
+                                                 const uint32_t *__restrict__ cell_ids) {
     if (*rebuild == 0u) return;
-    reorder_body(pk, velk, slot, cell_start, pos, pos_ref, vel, id, skey, (int)dn[0], block_sums, scan_tiles);
+    reorder_body(pk, velk, slot, cell_start, pos, pos_ref, vel, id, skey, (int)dn[0], block_sums, scan_tiles, cell_ids);
 }
 
-void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
+void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool deterministic) {
     if (cap <= 0) return;
     const int scan_tiles = (c.n_cells + 1 + SCAN_TILE - 1) / SCAN_TILE * SCAN_SPREAD;      // counters to zero
+    uint32_t *cell_ids = deterministic ? a.nlist : nullptr;      // (the lists are rebuilt after the scatter: free until then)
+    if (deterministic)
+        hipLaunchKernelGGL(k_cell_ids, dim3(gated_grid((cap + BLK - 1) / BLK)), dim3(BLK), 0, st, a.pk, a.slot, a.cell_start, cell_ids, a.dn, a.rebuild);
     hipLaunchKernelGGL(k_reorder, dim3(gated_grid((cap + BLK - 1) / BLK)), dim3(BLK), 0, st, a.pk, a.velk, a.slot, a.cell_start, a.pos,
-                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.rebuild, a.block_sums, scan_tiles);
+                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.rebuild, a.block_sums, scan_tiles, cell_ids);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -946,13 +974,23 @@ __global__ __launch_bounds__(BLK) void k_boundary_reorder(const float2 *__restri
                                                           const uint32_t *__restrict__ slot,
                                                           const uint32_t *__restrict__ cell_start,
                                                           float2 *__restrict__ bpos, uint32_t *__restrict__ bid, int nb,
-                                                          const float2 *__restrict__ bvel_in, float2 *__restrict__ bvel) {
+                                                          const float2 *__restrict__ bvel_in, float2 *__restrict__ bvel,
+                                                          const uint32_t *__restrict__ cell_ids) {
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= nb) return;
-    uint32_t dst = cell_start[key[i]] + slot[i];
+    // the order inside a cell: by index (the slots were handed out in the order the atomics arrived)
+    const uint32_t k = key[i], beg = cell_start[k], end = cell_start[k + 1];
+    uint32_t dst = beg;
+    for (uint32_t j = beg; j < end; j++) dst += cell_ids[j] < (uint32_t)i ? 1u : 0u;
     bpos[dst] = bpos_in[i];
     bvel[dst] = bvel_in[i];
     bid[dst] = (uint32_t)i;
+}
+// the members of every cell, in slot order (input of the deterministic rank above / in reorder_body)
+__global__ __launch_bounds__(BLK) void k_boundary_cell_ids(const uint32_t *__restrict__ key, const uint32_t *__restrict__ slot,
+                                                           const uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cell_ids, int nb) {
+    int i = blockIdx.x * BLK + threadIdx.x;
+    if (i < nb) cell_ids[cell_start[key[i]] + slot[i]] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(BLK) void k_boundary_psi(Consts c, const float2 *__restrict__ bpos,
@@ -1024,10 +1062,11 @@ void launch_boundary_key(hipStream_t st, const Consts &c, const float2 *bpos_in,
 }
 void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32_t *key, const uint32_t *slot,
                              const uint32_t *cell_start, float2 *bpos, uint32_t *bid, int nb, const float2 *bvel_in,
-                             float2 *bvel) {
+                             float2 *bvel, uint32_t *cell_ids_tmp) {
     if (nb <= 0) return;
+    hipLaunchKernelGGL(k_boundary_cell_ids, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, key, slot, cell_start, cell_ids_tmp, nb);
     hipLaunchKernelGGL(k_boundary_reorder, dim3((nb + BLK - 1) / BLK), dim3(BLK), 0, st, bpos_in, key, slot, cell_start,
-                       bpos, bid, nb, bvel_in, bvel);
+                       bpos, bid, nb, bvel_in, bvel, cell_ids_tmp);
 }
 void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb) {
     if (nb <= 0) return;

@@ -13,6 +13,7 @@ void sph_params_default(sph_params *p) {
     p->x_min = 0.0f; p->x_max = 4.0f;    /* WIDTH  :13 */
     p->y_min = 0.0f; p->y_max = 2.0f;    /* HEIGHT :14 */
     p->alpha = 0.01f; p->eps = 0.01f; p->k1 = 0.1f; p->k2 = 0.2f;   /* :325, :332, :334 */
+    p->deterministic = 0;
     p->skin = 0.15f;                 /* neighbour-structure reuse; 0.15 measured best on the 2M-particle dam break */
 }
 

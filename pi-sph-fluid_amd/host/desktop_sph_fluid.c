@@ -9,7 +9,7 @@
  *
  *   desktop_sph_fluid [--scene cfg0|cfg1|cfg2|cfg3|cfg4] [--steps N] [--realtime] [--tilt]
  *                     [--tilt-amp DEG] [--tilt-period S] [--tilt-hold S] [--mpu6050 DIR] [--show] [--batch K]
- *                     [--device D] [--skin F] [--dump-frame FILE] [--dump-state FILE]
+ *                     [--device D] [--skin F] [--deterministic] [--dump-frame FILE] [--dump-state FILE]
  * --dump-frame: the 1024-byte SSD1306 page-format frame of the final state (what ssd1306_drawBufferFast would be
  * handed, :469); --dump-state: the final fluid[] array (struct particle, 28 bytes each, :26-31).
  */
@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
     int realtime = 0, show = 0, batch = 1, device = 0, gkind = SPH_GRAVITY_CONSTANT;
     const char *mpu_dir = NULL, *dump_frame = NULL, *dump_state = NULL;
     float tilt_amp = -1, tilt_period = -1, tilt_hold = -1, skin = -1;
+    int deterministic = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) max_steps = atol(argv[++i]);
@@ -64,6 +65,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--tilt-period") && i + 1 < argc) tilt_period = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--tilt-hold") && i + 1 < argc) tilt_hold = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--skin") && i + 1 < argc) skin = (float)atof(argv[++i]);
+        else if (!strcmp(argv[i], "--deterministic")) deterministic = 1;
         else if (!strcmp(argv[i], "--dump-frame") && i + 1 < argc) dump_frame = argv[++i];
         else if (!strcmp(argv[i], "--dump-state") && i + 1 < argc) dump_state = argv[++i];
         else if (!strcmp(argv[i], "--mpu6050") && i + 1 < argc) { gkind = SPH_GRAVITY_MPU6050; mpu_dir = argv[++i]; }
@@ -74,6 +76,7 @@ int main(int argc, char **argv) {
     /* ---- scene (:484-540) ---- */
     sph_params prm;
     sph_params_default(&prm);
+    prm.deterministic = deterministic;
     if (skin >= 0) prm.skin = skin;
     long n_fluid = 0, n_boundary = 0;
     sph_particle *fluid = NULL, *boundary = NULL;

@@ -14,7 +14,7 @@
  * Everything is enqueued on HIP streams; the host synchronises only around the timed region.
  *
  *   slab_sph_fluid --ranks N [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--steps K] [--warmup W] [--tilt]
- *                  [--check]
+ *                  [--check] [--deterministic] [--skin F]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device r.
  * The ncclUniqueId travels through a file (--id-file, made by the launcher).  --scene dam: N lattice blocks of
  * 4000 x 500 (2 000 000 particles per GPU, box 1200 N x 60 m: the cfg2 -> cfg3 weak-scaling family); cfg3 / cfg4: the
@@ -132,7 +132,8 @@ static float max_abs_diff(const sph_particle *a, const sph_particle *b, const un
 }
 
 int main(int argc, char **argv) {
-    int nranks = 1, rank = -1, steps = 200, warmup = 50, tilt = 0, check = 0;
+    int nranks = 1, rank = -1, steps = 200, warmup = 50, tilt = 0, check = 0, deterministic = 0;
+    float skin = -1;
     const char *scene_name = "dam", *idfile = NULL;
     scene_t sc = {0, 0, 0.3f, 0.3f, 0, 0, NULL};
     for (int i = 1; i < argc; i++) {
@@ -143,6 +144,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tilt")) tilt = 1;
+        else if (!strcmp(argv[i], "--deterministic")) deterministic = 1;
+        else if (!strcmp(argv[i], "--skin") && i + 1 < argc) skin = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--check")) check = 1;
         else if (!strcmp(argv[i], "--block") && i + 4 < argc) {
             sc.nx = atol(argv[++i]); sc.ny = atol(argv[++i]); sc.box_w = (float)atof(argv[++i]); sc.box_h = (float)atof(argv[++i]);
@@ -163,6 +166,8 @@ int main(int argc, char **argv) {
     }
     sph_params prm;
     sph_params_default(&prm);
+    prm.deterministic = deterministic;
+    if (skin >= 0) prm.skin = skin;
     prm.x_max = sc.box_w;
     prm.y_max = sc.box_h;
     int *cuts = (int *)calloc((size_t)nranks + 1, sizeof(int));

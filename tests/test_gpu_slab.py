@@ -234,3 +234,32 @@ def test_rebalance_keeps_a_migrating_flow_inside_capacity(sph):
     assert np.abs(ref["x"] - f["x"]).min() > 5.0                                  # the block really travelled
     assert max(np.abs(out["x"] - ref["x"]).max(), np.abs(out["y"] - ref["y"]).max()) <= 2e-4
     assert np.max(np.abs(out["rho"] - ref["rho"]) / ref["rho"]) <= 1e-3
+
+
+def test_deterministic_slabs_equal_single_bitwise(sph, orc):
+    """With sph_params.deterministic the order of a cell's particles does not depend on who binned them, and a particle's
+    neighbours are summed in the order of the interleaved window (cell row, column, id): three slabs give the SAME BITS as
+    one context, through rebuilds and migration — as long as both rebuild in the same steps, hence skin 0 here (with a
+    skin a slab may rebuild a step earlier than the single context: waves next to ghosts use the absolute criterion)."""
+    g = load_golden("block.npz")
+    prm = sph.default_params(tuple(g["box"]), 0.0, deterministic=True)
+    f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))
+    b = boundary_particles(orc, g["boundary_xy"])
+    slabs, runner = build(sph, prm, f, b, 3)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        done = 0
+        for k in (0, 1, 40, 150):
+            ctx.step(k - done, GX, GY)
+            ctx.sync()
+            runner.step(k - done, GX, GY)
+            done = k
+            ref = ctx.read_particles()
+            rdu, rdv = ctx.read_accel()
+            out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+            assert np.all(seen == 1), k
+            for name in ("x", "y", "u", "v", "rho", "p"):
+                assert np.array_equal(out[name], ref[name]), (k, name, np.abs(out[name] - ref[name]).max())
+            assert np.array_equal(du, rdu) and np.array_equal(dv, rdv), k
+        assert ctx.rebuild_stats()[0] >= 150
+    for s in slabs:
+        s.close()

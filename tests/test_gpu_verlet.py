@@ -203,3 +203,28 @@ def test_two_contexts_on_one_device_use_separate_launches(sph, orc):
             assert not c1.rebuild_launches() and not c2.rebuild_launches()
             a, b2 = c1.read_particles(), c2.read_particles()
             assert np.all(np.isfinite(a["x"])) and np.all(np.isfinite(b2["x"]))
+
+
+def test_deterministic_runs_are_bit_identical(sph, orc):
+    """sph_params.deterministic: the particles of a cell in id order -> the same bits from run to run (without it the
+    order follows the arrival of the binning atomics and results agree to rounding only), and still the oracle's
+    trajectory."""
+    g = load_golden("block.npz")
+    prm = sph.default_params(tuple(g["box"]), 0.05, deterministic=True)      # a thin skin: many rebuilds
+    xy = g["fluid_xy0"]
+    f = particles(orc, np.concatenate([xy, np.zeros_like(xy)], 1), m_fluid(prm))
+    b = boundary_particles(orc, g["boundary_xy"])
+    runs = []
+    for one_launch in (True, False, True):
+        with sph.Context(prm, f, b, GX, GY) as ctx:
+            ctx.set_rebuild_launches(one_launch)
+            a0 = ctx.read_accel()
+            ctx.step(400, GX, GY)
+            ctx.sync()
+            runs.append((ctx.read_particles(), ctx.read_accel(), a0, ctx.rebuild_stats()[0]))
+    for got, acc, a0, reb in runs[1:]:
+        for k in ("x", "y", "u", "v", "rho", "p"):
+            assert np.array_equal(got[k], runs[0][0][k]), k
+        assert np.array_equal(acc[0], runs[0][1][0]) and np.array_equal(acc[1], runs[0][1][1])
+        assert np.array_equal(a0[0], runs[0][2][0]) and reb == runs[0][3]
+    assert runs[0][3] > 3

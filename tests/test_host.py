@@ -22,12 +22,12 @@ def test_abi_library_loads_and_exports_every_declared_symbol(sph):
     hdecl = set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", hheader))
     for name in hdecl:
         assert hasattr(H, name), name
-    assert L.sph_abi_version() == 3
+    assert L.sph_abi_version() == 4
 
 
 def test_struct_layouts(sph):
     assert sph.PARTICLE.itemsize == 28                       # struct particle :26-31
-    assert C.sizeof(sph.Params) == 16 * 4
+    assert C.sizeof(sph.Params) == 17 * 4
     assert C.sizeof(sph.KernelTimes) == 8 * 4 + 4 + 4 + 4
 
 

@@ -95,3 +95,14 @@ def test_c_host_two_ranks_over_rccl(sph):
     rec = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 2 and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True
     assert rec["ticks_per_s"] > 0 and 0 < rec["neighbour_rebuilds"] < 400
+
+
+@pytest.mark.gpu
+def test_c_host_deterministic_equals_sph_step_bitwise(sph):
+    """--deterministic (sph_params.deterministic): the slab path through the C host and sph_step give the same bits when
+    they rebuild in the same steps (skin 0: every step; with a skin the slab path may rebuild a step earlier)"""
+    r = subprocess.run([HOST, "--ranks", "1", "--block", "600", "150", "90", "20", "--steps", "150", "--warmup", "50", "--check",
+                        "--deterministic", "--skin", "0"], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    chk = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("check:")]
+    assert len(chk) == 1 and "max|dx| = 0.000e+00" in chk[0] and "max|drho| = 0.000e+00" in chk[0], chk
