@@ -76,11 +76,12 @@ typedef struct sph_ctx sph_ctx;
 
 /* names of the per-step kernels, in launch order (index into sph_kernel_times.ms).  The kernels marked [R] are
  * the rebuild of the neighbour structure (the reference's update_neighbors_context :104-124 + find_neighbors
- * :126-153): they are launched every step and return at once unless kick/drift asked for a rebuild. */
+ * :126-153): they return at once unless a rebuild was asked for.  sph_step launches them as ONE kernel with grid
+ * barriers between the phases (sph_set_rebuild_launches); sph_profile_steps, which times them one by one, as four. */
 enum {
     SPH_K_KICK_DRIFT     = 0,  /* :615-624 in place; requests a rebuild when a particle moved > skin/2 since the last */
     SPH_K_KEY_HIST       = 1,  /* [R] cell index of :111-113 + histogram (counting sort pass 1)      */
-    SPH_K_SCAN           = 2,  /* [R] counting sort: exclusive scan -> cell_start (two launches)     */
+    SPH_K_SCAN           = 2,  /* [R] counting sort: exclusive scan -> cell_start                    */
     SPH_K_REORDER        = 3,  /* [R] counting sort: scatter to cell-contiguous order (replaces the linked list of :104-124) */
     SPH_K_BUILD_LIST     = 4,  /* [R] find_neighbors :126-153 once per rebuild: per-particle neighbour lists */
     SPH_K_DENSITY_EOS    = 5,  /* :263-289 + :294-301                            */
