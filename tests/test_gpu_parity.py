@@ -498,3 +498,29 @@ def test_time_kernel_needs_a_step(sph):
         ctx.upload_state(before)
         with pytest.raises(sph.SphError):
             ctx.time_kernel("force_kick", 2)
+
+
+def test_request_rebuild_and_timed_list_build(sph, orc, oracle):
+    """sph_request_rebuild forces a rebuild in the next step whatever the criterion says; sph_time_kernel('build_list')
+    rebuilds the lists in place and leaves the request raised.  Neither changes the trajectory beyond summation order."""
+    g = load_golden("block.npz")
+    prm = sph.default_params(tuple(g["box"]))
+    f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))
+    b = boundary_particles(orc, g["boundary_xy"])
+    with sph.Context(prm, f, b, GX, GY) as ctx, sph.Context(prm, f, b, GX, GY) as ref:
+        r0 = ctx.rebuild_stats()[0]
+        for _ in range(5):
+            ctx.request_rebuild()
+            ctx.step(1, GX, GY)
+        ctx.sync()
+        assert ctx.rebuild_stats()[0] - r0 == 5
+        assert ctx.time_kernel("build_list", 3) > 0
+        r1 = ctx.rebuild_stats()[0]
+        ctx.step(1, GX, GY)                       # finds the request raised: a full rebuild
+        ctx.sync()
+        assert ctx.rebuild_stats()[0] - r1 >= 1 and ctx.rebuild_stats()[1] == 0
+        ref.step(6, GX, GY)
+        ref.sync()
+        a, r = ctx.read_particles(), ref.read_particles()
+        assert max(np.abs(a["x"] - r["x"]).max(), np.abs(a["y"] - r["y"]).max()) <= 2e-5
+        assert np.max(np.abs(a["rho"] - r["rho"]) / r["rho"]) <= 2e-4

@@ -77,6 +77,7 @@ def test_slab_errors(sph):
     s = sph.slab.GpuSlab(sph, prm, f, b, 0, 60, False, True, GX, GY)
     L = sph.hip_lib()
     assert L.sph_step(s.h, 0.0, -9.81, 1) == sph.SPH_E_STATE          # single-GPU entry point on a slab
+    assert L.sph_request_rebuild(s.h) == sph.SPH_E_STATE              # (slabs: the reduced word, sph_slab_flag_set)
     assert L.sph_slab_step_end(s.h) == sph.SPH_E_STATE                # end without begin
     assert L.sph_slab_step_pack(s.h) == sph.SPH_E_STATE               # pack without begin
     s.step_begin(GX, GY)
