@@ -17,7 +17,7 @@ def build(sph, prm, f, b, world, slack=8):
 @pytest.mark.parametrize("world", [2, 3])
 def test_developed_block_slabs_vs_single(sph, orc, world):
     g = load_golden("block.npz")
-    prm = sph.default_params(tuple(g["box"]))
+    prm = sph.default_params(tuple(g["box"]), deterministic=True)      # (a chaotic flow compared at 150 steps: same bits every run)
     f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))
     b = boundary_particles(orc, g["boundary_xy"])
     slabs, runner = build(sph, prm, f, b, world)

@@ -22,7 +22,7 @@ def test_translating_box_against_oracle(sph, orc, oracle):
     g = load_golden("block.npz")
     gb0 = tuple(g["box"])
     box = (gb0[0], gb0[1] + 2.0, gb0[2], gb0[3] + 2.0)
-    prm = sph.default_params(box)
+    prm = sph.default_params(box, deterministic=True)      # (the live comparison below is of a chaotic flow: same bits every run)
     walls = boundary_particles(orc, g["boundary_xy"] + np.float32(1.0))
     f = particles(orc, g["state"] + np.array([1.0, 1.0, 0.0, 0.0], np.float32), np.float32(prm.rho0) * np.float32(prm.vol))
     p = oracle.params(box)
