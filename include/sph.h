@@ -136,6 +136,10 @@ int  sph_read_boundary(sph_ctx *ctx, sph_particle *out);
  * wall neighbourhood).  Call between steps; the next step rebuilds the fluid's neighbour structure against the new bins.
  * The walls must stay inside the domain box. */
 int  sph_update_boundary(sph_ctx *ctx, const sph_particle *boundary);
+/* every wall particle moves with (u, v) from now on: the velocity the wall viscosity term (:357) sees.  Positions stay
+ * (sph_update_boundary moves walls); nothing is re-binned or rebuilt, so this is cheap enough for every step, e.g. with
+ * the velocity a host infers from its accelerometer (sph_wall_motion, include/sph_host.h; README.md:175-176). */
+int  sph_set_boundary_velocity(sph_ctx *ctx, float u, float v);
 /* the statistics of :657-671 as device reductions: max rho and max sqrt(u^2+v^2) over fluid */
 int  sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed);
 

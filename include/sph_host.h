@@ -88,6 +88,23 @@ void sph_gravity_init(sph_gravity *gs, int kind, float g);
  * Returns 0, or SPH_E_ARG when the MPU6050 files cannot be read (reference: exit(1), :419-422). */
 int  sph_gravity_sample(sph_gravity *gs, float t, float *gx, float *gy);
 
+/* ---- wall velocity inferred from the accelerometer (the reference's README, "What's not implemented?" item 2,
+ * README.md:175-176; the velocity enters the wall viscosity term pi_sph_fluid.c:357 through sph_set_boundary_velocity) ----
+ * The accelerometer reports gravity as seen from the box.  Its slow part is the tilt (a first-order low pass with time
+ * constant tau_tilt follows it); what remains is the linear acceleration of the box, which a leaky integrator (time
+ * constant tau_leak: without the leak sensor bias would make the velocity drift) turns into the box's velocity:
+ *     g_lp += (g - g_lp) dt / tau_tilt;   a = -(g - g_lp);   v = (v + a dt) exp(-dt / tau_leak)                     */
+typedef struct sph_wall_motion {
+    float tau_tilt;   /* [s], default 0.5 */
+    float tau_leak;   /* [s], default 1.0 */
+    float glx, gly;   /* low-passed gravity */
+    float vx, vy;     /* inferred velocity of the box */
+    int   primed;
+} sph_wall_motion;
+void sph_wall_motion_init(sph_wall_motion *wm);
+/* one gravity sample (gx, gy) valid for the last dt seconds -> the box's velocity */
+void sph_wall_motion_update(sph_wall_motion *wm, float gx, float gy, float dt, float *vx, float *vy);
+
 #ifdef __cplusplus
 }
 #endif

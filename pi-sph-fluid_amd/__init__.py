@@ -36,7 +36,7 @@ STEP_ALGO_BYTES = 152.0
 ABI_SYMBOLS = [
     "sph_params_default", "sph_abi_version", "sph_error_string", "sph_device_count",
     "sph_create", "sph_destroy", "sph_last_error", "sph_step", "sph_sync",
-    "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_stats",
+    "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_set_boundary_velocity", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
     "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_get_rebuild_launches", "sph_rebuild_stats", "sph_check_stats",
     "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
 HOST_SYMBOLS = [
     "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",
     "sph_scene_block_range", "sph_scene_walls_layers",
-    "sph_gravity_init", "sph_gravity_sample",
+    "sph_gravity_init", "sph_gravity_sample", "sph_wall_motion_init", "sph_wall_motion_update",
     "sph_slab_grid_columns", "sph_slab_column_of", "sph_slab_partition_block", "sph_slab_block_columns",
 ]
 
@@ -80,6 +80,11 @@ class Gravity(C.Structure):
 
 
 GRAVITY_CONSTANT, GRAVITY_TILT, GRAVITY_MPU6050 = 0, 1, 2
+
+
+class WallMotionState(C.Structure):
+    _fields_ = [("tau_tilt", C.c_float), ("tau_leak", C.c_float), ("glx", C.c_float), ("gly", C.c_float),
+                ("vx", C.c_float), ("vy", C.c_float), ("primed", C.c_int)]
 
 
 class SphError(RuntimeError):
@@ -122,6 +127,7 @@ def hip_lib():
         L.sph_read_accel.argtypes = [vp, vp, vp]
         L.sph_read_boundary.argtypes = [vp, vp]
         L.sph_update_boundary.argtypes = [vp, vp]
+        L.sph_set_boundary_velocity.argtypes = [vp, C.c_float, C.c_float]
         L.sph_stats.argtypes = [vp, C.POINTER(cf), C.POINTER(cf)]
         L.sph_n_fluid.argtypes = [vp]
         L.sph_n_boundary.argtypes = [vp]
@@ -194,6 +200,10 @@ def host_lib():
         L.sph_gravity_init.argtypes = [C.POINTER(Gravity), C.c_int, cf]
         L.sph_gravity_init.restype = None
         L.sph_gravity_sample.argtypes = [C.POINTER(Gravity), cf, C.POINTER(cf), C.POINTER(cf)]
+        L.sph_wall_motion_init.argtypes = [C.POINTER(WallMotionState)]
+        L.sph_wall_motion_init.restype = None
+        L.sph_wall_motion_update.argtypes = [C.POINTER(WallMotionState), cf, cf, cf, C.POINTER(cf), C.POINTER(cf)]
+        L.sph_wall_motion_update.restype = None
         _host = L
     return _host
 
@@ -306,6 +316,24 @@ class GravitySource:
         return gx.value, gy.value
 
 
+class WallMotion:
+    """sph_wall_motion (include/sph_host.h): the velocity of the box inferred from the accelerometer's gravity samples
+    (README.md:175-176), to be handed to Context.set_boundary_velocity."""
+
+    def __init__(self, tau_tilt=None, tau_leak=None):
+        self.s = WallMotionState()
+        host_lib().sph_wall_motion_init(C.byref(self.s))
+        if tau_tilt is not None:
+            self.s.tau_tilt = tau_tilt
+        if tau_leak is not None:
+            self.s.tau_leak = tau_leak
+
+    def update(self, gx, gy, dt):
+        vx, vy = C.c_float(), C.c_float()
+        host_lib().sph_wall_motion_update(C.byref(self.s), gx, gy, dt, C.byref(vx), C.byref(vy))
+        return vx.value, vy.value
+
+
 class Context:
     """One sph_ctx: the init/step/read-back surface of include/sph.h."""
 
@@ -369,6 +397,10 @@ class Context:
         boundary = np.ascontiguousarray(boundary, PARTICLE)
         assert len(boundary) == self.nb
         self._chk(self.L.sph_update_boundary(self.h, boundary.ctypes.data_as(C.c_void_p)))
+
+    def set_boundary_velocity(self, u, v):
+        """every wall particle moves with (u, v): what the wall viscosity term sees; nothing is re-binned"""
+        self._chk(self.L.sph_set_boundary_velocity(self.h, u, v))
 
     def stats(self):
         a, b = C.c_float(), C.c_float()

@@ -683,6 +683,17 @@ int sph_update_boundary(sph_ctx *ctx, const sph_particle *boundary) {
     return check_flags(ctx);
 }
 
+int sph_set_boundary_velocity(sph_ctx *ctx, float u, float v) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (!(std::isfinite(u) && std::isfinite(v))) return fail(ctx, SPH_E_ARG, "sph_set_boundary_velocity: velocity not finite");
+    if (ctx->slab && ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_set_boundary_velocity mid-step");
+    (void)hipSetDevice(ctx->device);
+    launch_fill_float2(ctx->stream, ctx->a.bvel, u, v, ctx->nb);            // bin order: what the force pass reads
+    launch_fill_float2(ctx->stream, ctx->d_bvel_in, u, v, ctx->nb);         // original order: what sph_update_boundary re-bins
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
 int sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);

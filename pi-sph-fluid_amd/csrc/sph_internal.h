@@ -204,6 +204,7 @@ void launch_boundary_reorder(hipStream_t st, const float2 *bpos_in, const uint32
 void launch_boundary_psi(hipStream_t st, const Consts &c, const Arrays &a, int nb);
 // per-cell flag "walls within reach" from the wall bins (init; again whenever the walls are re-binned)
 void launch_boundary_near(hipStream_t st, const Consts &c, const Arrays &a);
+void launch_fill_float2(hipStream_t st, float2 *dst, float x, float y, int n);
 void launch_boundary_gather_psi(hipStream_t st, const Arrays &a, const float *psi_in_original_order, int nb);
 void launch_boundary_unsort_psi(hipStream_t st, const Arrays &a, float *psi_out_original_order, int nb);
 // read-back helpers

@@ -1029,6 +1029,13 @@ __global__ __launch_bounds__(BLK) void k_boundary_near(Consts c, const uint32_t 
     for (int cc = max(col - 1, 0); cc <= min(col + 1, c.cols - 1); cc++) cnt += bcs[cc * c.rows + r1 + 1] - bcs[cc * c.rows + r0];
     bnear[cell] = cnt ? 1 : 0;
 }
+__global__ __launch_bounds__(BLK) void k_fill_float2(float2 *__restrict__ dst, float x, float y, int n) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i < n) dst[i] = make_float2(x, y);
+}
+void launch_fill_float2(hipStream_t st, float2 *dst, float x, float y, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_fill_float2, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, st, dst, x, y, n);
+}
 void launch_boundary_near(hipStream_t st, const Consts &c, const Arrays &a) {
     hipLaunchKernelGGL(k_boundary_near, dim3((c.n_cells + BLK - 1) / BLK), dim3(BLK), 0, st, c, a.bcell_start, a.bnear);
 }

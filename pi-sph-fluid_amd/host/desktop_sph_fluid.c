@@ -9,7 +9,7 @@
  *
  *   desktop_sph_fluid [--scene cfg0|cfg1|cfg2|cfg3|cfg4] [--steps N] [--realtime] [--tilt]
  *                     [--tilt-amp DEG] [--tilt-period S] [--tilt-hold S] [--mpu6050 DIR] [--show] [--batch K]
- *                     [--device D] [--skin F] [--deterministic] [--dump-frame FILE] [--dump-state FILE]
+ *                     [--device D] [--skin F] [--deterministic] [--wall-velocity] [--dump-frame FILE] [--dump-state FILE]
  * --dump-frame: the 1024-byte SSD1306 page-format frame of the final state (what ssd1306_drawBufferFast would be
  * handed, :469); --dump-state: the final fluid[] array (struct particle, 28 bytes each, :26-31).
  */
@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
     int realtime = 0, show = 0, batch = 1, device = 0, gkind = SPH_GRAVITY_CONSTANT;
     const char *mpu_dir = NULL, *dump_frame = NULL, *dump_state = NULL;
     float tilt_amp = -1, tilt_period = -1, tilt_hold = -1, skin = -1;
-    int deterministic = 0;
+    int deterministic = 0, wall_velocity = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) max_steps = atol(argv[++i]);
@@ -66,6 +66,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--tilt-hold") && i + 1 < argc) tilt_hold = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--skin") && i + 1 < argc) skin = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--deterministic")) deterministic = 1;
+        else if (!strcmp(argv[i], "--wall-velocity")) wall_velocity = 1;    /* README.md:175-176: infer it from the accelerometer */
         else if (!strcmp(argv[i], "--dump-frame") && i + 1 < argc) dump_frame = argv[++i];
         else if (!strcmp(argv[i], "--dump-state") && i + 1 < argc) dump_state = argv[++i];
         else if (!strcmp(argv[i], "--mpu6050") && i + 1 < argc) { gkind = SPH_GRAVITY_MPU6050; mpu_dir = argv[++i]; }
@@ -114,6 +115,8 @@ int main(int argc, char **argv) {
     if (tilt_period > 0) grav.period_s = tilt_period;
     if (tilt_hold >= 0) grav.hold_s = tilt_hold;
     float gx, gy;
+    sph_wall_motion wmotion;
+    sph_wall_motion_init(&wmotion);
     int rc = sph_gravity_sample(&grav, 0.0f, &gx, &gy);
     if (rc) return die(NULL, "sph_gravity_sample", rc);
 
@@ -168,6 +171,12 @@ int main(int argc, char **argv) {
         }
         rc = sph_gravity_sample(&grav, t, &gx, &gy);                               /* 10 Hz hold, :455-461 */
         if (rc) return die(ctx, "sph_gravity_sample", rc);
+        if (wall_velocity) {                                                       /* README.md:175-176 */
+            float wvx, wvy;
+            sph_wall_motion_update(&wmotion, gx, gy, (float)k * prm.dt, &wvx, &wvy);
+            rc = sph_set_boundary_velocity(ctx, wvx, wvy);
+            if (rc) return die(ctx, "sph_set_boundary_velocity", rc);
+        }
         if (realtime) {                                                            /* :694-701 */
             sph_sync(ctx);
             do { now = now_s(); } while (now - last_stepped < (double)k * prm.dt - 30e-6);

@@ -58,3 +58,27 @@ int sph_gravity_sample(sph_gravity *gs, float t, float *gx, float *gy) {
     *gx = gs->gx; *gy = gs->gy;
     return SPH_OK;
 }
+
+/* ---- wall velocity from the accelerometer (sph_host.h) ---- */
+void sph_wall_motion_init(sph_wall_motion *wm) {
+    memset(wm, 0, sizeof *wm);
+    wm->tau_tilt = 0.5f;
+    wm->tau_leak = 1.0f;
+}
+
+void sph_wall_motion_update(sph_wall_motion *wm, float gx, float gy, float dt, float *vx, float *vy) {
+    if (!wm->primed) {            /* the first sample is all tilt */
+        wm->glx = gx;
+        wm->gly = gy;
+        wm->primed = 1;
+    }
+    const float k = wm->tau_tilt > 0 ? fminf(dt / wm->tau_tilt, 1.0f) : 1.0f;
+    wm->glx += (gx - wm->glx) * k;
+    wm->gly += (gy - wm->gly) * k;
+    const float ax = -(gx - wm->glx), ay = -(gy - wm->gly);       /* the box accelerates against the apparent gravity change */
+    const float leak = wm->tau_leak > 0 ? expf(-dt / wm->tau_leak) : 0.0f;
+    wm->vx = (wm->vx + ax * dt) * leak;
+    wm->vy = (wm->vy + ay * dt) * leak;
+    *vx = wm->vx;
+    *vy = wm->vy;
+}

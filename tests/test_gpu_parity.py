@@ -436,6 +436,36 @@ def test_wall_velocity_enters_the_viscosity_term(sph, orc, oracle, variant):
     assert np.max(np.hypot(odu - g["eval_du_2000"], odv - g["eval_dv_2000"])) > 1e-2    # the wall velocity matters
 
 
+def test_set_boundary_velocity_against_oracle(sph, orc, oracle):
+    """sph_set_boundary_velocity: every wall particle gets (u, v) without re-binning (the velocity a host infers from its
+    accelerometer, README.md:175-176): the staged G3 gate against the oracle run with the same wall velocities, the
+    read-back of the walls, and a step afterwards still using them."""
+    g = load_golden("drop.npz")
+    box = (0.0, 4.0, 0.0, 2.0)
+    state, rho_ref, p_ref = g["state_2000"], g["rho_2000"], g["p_2000"]     # fluid resting on the floor
+    prm = sph.default_params(box)
+    b = boundary_particles(orc, g["boundary_xy"])
+    fin = particles(orc, state, m_fluid(prm), rho=rho_ref, p=p_ref)
+    with sph.Context(prm, fin, b, GX, GY) as ctx:
+        ctx.set_boundary_velocity(2.5, -0.4)
+        gb = ctx.read_boundary()
+        assert np.all(gb["u"] == np.float32(2.5)) and np.all(gb["v"] == np.float32(-0.4))
+        assert np.array_equal(gb["x"], b["x"]) and np.array_equal(gb["y"], b["y"])      # nobody moved
+        ctx.upload_state(fin)
+        ctx.eval_accel(GX, GY)
+        du, dv = ctx.read_accel()
+        ctx.step(3, GX, GY)                                                   # (the step's force pass reads the same array)
+        ctx.sync()
+        assert np.all(ctx.read_boundary()["u"] == np.float32(2.5))
+    bpsi = b.copy()
+    bpsi["m"] = g["psi"]
+    bpsi["u"] = 2.5
+    bpsi["v"] = -0.4
+    odu, odv, sa = sum_abs_terms(oracle, box, fin, bpsi)
+    assert np.max(np.hypot(du - odu, dv - odv) / (sa + G)) <= TOL
+    assert np.max(np.hypot(odu - g["eval_du_2000"], odv - g["eval_dv_2000"])) > 1e-2    # the wall velocity matters
+
+
 def test_restart_from_read_back_continues_the_run(sph, orc):
     """checkpoint / resume: sph_upload_state(sph_read_particles()) keeps du_dt, dv_dt aligned with their particles (the
     reference's arrays are index-aligned, :616), so stepping on continues the uninterrupted run; a fresh context needs

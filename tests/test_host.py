@@ -163,3 +163,29 @@ def test_multi_layer_wall_generator(sph):
     assert len(three) > 3 * len(one)                                     # outer frames are longer
     L = sph.host_lib()
     assert L.sph_scene_walls_layers(C.byref(prm), 0.05, 5.5, 0.5, 3.5, 2, None, 0) == sph.SPH_E_ARG      # outer frame leaves the box
+
+
+def test_wall_motion_from_accelerometer(sph):
+    """sph_wall_motion (README.md:175-176): a constant tilt gives no velocity; a jolt of the box shows up as a velocity
+    of the right sign and size, which leaks away afterwards; the numbers follow the documented recurrence."""
+    wm = sph.WallMotion()
+    dt = 1e-3
+    for _ in range(2000):                                  # the box at rest, tilted by 10 degrees
+        v = wm.update(9.81 * np.sin(np.radians(10)), -9.81 * np.cos(np.radians(10)), dt)
+    assert abs(v[0]) < 1e-6 and abs(v[1]) < 1e-6
+    gx0, gy0 = 9.81 * np.sin(np.radians(10)), -9.81 * np.cos(np.radians(10))
+    # a 50 ms jolt: the box accelerates at +4 m/s^2 along x, so apparent gravity gains -4 m/s^2 along x
+    ref = dict(glx=np.float32(gx0), gly=np.float32(gy0), vx=np.float32(v[0]), vy=np.float32(v[1]))
+    for k in range(50):
+        gx = gx0 - 4.0
+        v = wm.update(gx, gy0, dt)
+        kk = np.float32(min(dt / 0.5, 1.0))
+        ref["glx"] = np.float32(ref["glx"] + (np.float32(gx) - ref["glx"]) * kk)
+        ax = np.float32(-(np.float32(gx) - ref["glx"]))
+        ref["vx"] = np.float32((ref["vx"] + ax * np.float32(dt)) * np.float32(np.exp(np.float32(-dt / 1.0))))
+    assert v[0] == pytest.approx(float(ref["vx"]), rel=1e-4)
+    assert 0.15 < v[0] < 0.2 and abs(v[1]) < 1e-6           # ~ 4 m/s^2 x 50 ms = 0.2 m/s, less what the low pass took for tilt
+    peak = v[0]
+    for _ in range(3000):                                  # at rest again: the velocity leaks away (and the filter's overshoot with it)
+        v = wm.update(gx0, gy0, dt)
+    assert abs(v[0]) < 0.1 * peak
