@@ -275,6 +275,8 @@ def run_c_host(sph, args):
     exchange and rebuild-word reduction over RCCL, no torch in the loop).  Started here as N ranks, or — under torchrun
     — as the one rank this process stands for (the ncclUniqueId then travels through a file named after the job)."""
     host = os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid")
+    if not os.path.exists(host):      # (normally built by __graft_entry__.build(); a fresh checkout builds it here)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "pi-sph-fluid_amd"), "all"], stdout=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "0"))
     scene = {"cfg2": "dam", "dam": "dam", "cfg3": "cfg3", "cfg4": "cfg4"}[args.workload]
     cmd = [host, "--scene", scene, "--steps", str(args.steps), "--warmup", str(args.warmup)]
