@@ -167,6 +167,11 @@ float sph_device_cell(const sph_params *prm);
 int   sph_request_rebuild(sph_ctx *ctx);
 /* rebuilds since creation, and tiles that list builds have put on the direct (no list) path */
 int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
+/* why list builds put tiles on the direct path so far, as counts: [0] the tile touches more column pairs than the build's
+ * tables hold, [1] more rows between its first and last particle than its row bitmap, [2] more runs of rows or cell-table
+ * entries, [3] more candidates than the LDS tile, [4] a candidate window longer than a list byte can index, [5] a
+ * neighbour list longer than the list capacity (measurement / diagnostics) */
+int   sph_direct_tile_reasons(sph_ctx *ctx, long long why[6]);
 /* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
 int   sph_check_stats(sph_ctx *ctx, long long *checks);
 /* total particles clamped into the domain so far (0 in a healthy run) */

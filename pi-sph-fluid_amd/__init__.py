@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_set_boundary_velocity", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
     "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_get_rebuild_launches", "sph_rebuild_stats", "sph_check_stats",
+    "sph_direct_tile_reasons",
     "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
     "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
     "sph_render_metaballs",
@@ -142,6 +143,7 @@ def hip_lib():
         L.sph_get_rebuild_launches.argtypes = [vp]
         L.sph_rebuild_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.sph_check_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
+        L.sph_direct_tile_reasons.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.sph_upload_state.argtypes = [vp, vp]
         L.sph_upload_accel.argtypes = [vp, vp, vp]
         L.sph_eval_density.argtypes = [vp]
@@ -444,6 +446,12 @@ class Context:
         a, b = C.c_longlong(), C.c_longlong()
         self._chk(self.L.sph_rebuild_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def direct_tile_reasons(self):
+        """why tiles went to the direct path so far: counts of (pairs, rows, runs / cell table, candidates, window, list length)."""
+        a = (C.c_longlong * 6)()
+        self._chk(self.L.sph_direct_tile_reasons(self.h, a))
+        return tuple(int(x) for x in a)
 
     def upload_state(self, fluid):
         fluid = np.ascontiguousarray(fluid, PARTICLE)

@@ -441,8 +441,9 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.skey, n); ALLOC(a.pos_ref, n);
     const size_t ntiles = (n + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES + 9;
     ALLOC(a.tiles, TILE_WORDS * ntiles); ALLOC(a.nlist, (size_t)LIST_WORDS_PER_TILE * ntiles);
-    ALLOC(a.wbase, ntiles * SPH_TILE_PARTICLES); ALLOC(a.stab, (size_t)STAB_ENTRIES_PER_TILE * ntiles);
+    ALLOC(a.lrec, ntiles * SPH_TILE_PARTICLES); ALLOC(a.stab, (size_t)STAB_ENTRIES_PER_TILE * ntiles);
     ALLOC(a.xranges, (size_t)XRANGE_WORDS * ntiles);
+    ALLOC(a.tstart, 4 * (ntiles + 1)); ALLOC(a.pext, (size_t)ctx->c.cols + 4);
     const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / BOXG);      // box groups
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     ALLOC(a.slot, n > nb ? n : nb);
@@ -749,6 +750,15 @@ int sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (rebuilds) *rebuilds = h[FLAG_NREBUILD];
     if (direct_tiles) *direct_tiles = h[FLAG_DIRECT_TILES];
+    return SPH_OK;
+}
+int sph_direct_tile_reasons(sph_ctx *ctx, long long why[6]) {
+    if (!ctx || !ctx->stream || !why) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    uint32_t h[6] = {0};
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags + FLAG_WHY_DIRECT, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 6; k++) why[k] = h[k];
     return SPH_OK;
 }
 int sph_check_stats(sph_ctx *ctx, long long *checks) {

@@ -63,8 +63,12 @@ struct Arrays {
     float2 *pos_ref;   // x,y at the last rebuild (the positions the neighbour lists were built from)
     uint32_t *tiles;   // one TILE_WORDS-word TileInfo record per 256-particle workgroup (sph_list.inc)
     uint32_t *nlist;   // neighbour lists: per tile LROWS4 rows x 256 lanes of 4 x 8-bit entries (sph_list.inc)
-    unsigned short *wbase; // per particle: first LDS slot of its candidate window (list entries are relative to it)
-    uint32_t *xranges;     // per tile XRANGE_WORDS: range table of the tiles with more than 6 candidate ranges
+    uint2 *lrec;           // per tile lane (tile * 256 + lane): .x = the lane's particle (index into the sorted arrays),
+                           // .y = first LDS slot of its candidate window (list entries are relative to it) | its own LDS slot << 16
+    uint32_t *tstart;      // per tile 4 words {column pair, row, index in column A, index in column B}: where the tile begins
+                           // in the tile order (sph_list.inc); entry [tiles] = the end of the last tile
+    uint32_t *pext;        // per column pair 2 words: first / last row that holds particles (valid for pairs that hold any)
+    uint32_t *xranges;     // per tile XRANGE_WORDS: range table of the tiles with more than 8 candidate ranges
     unsigned short *stab;  // staging table: per tile STAB_ENTRIES_PER_TILE LDS slots, one per staged candidate
     // staging (T)
     float4 *pk;        // x, y, id bits, cell key bits (after kick/drift, before the sort)
@@ -87,8 +91,8 @@ struct Arrays {
     float2 *grav;       // gravity vector read by the force kernel
     uint32_t *flags;    // see FLAG_*
     uint32_t *gbar;     // k_rebuild's grid barrier: GBAR_WORDS words, GBAR_STRIDE apart (arrivals, one per XCD, releases)
-    float4 *wbox;       // per group of BOXG consecutive sorted particles: bounding box of displacement since the last rebuild
-    uint32_t *wnbr;     // per group: WNBR_WORDS words = 5 x {first, last} group whose particles may come near this group's
+    float4 *wbox;       // per box group (BOXG consecutive lanes of a tile: a wave): bounding box of displacement since the last rebuild
+    uint32_t *wnbr;     // per group: WNBR_WORDS words = 6 x {first, last} group whose particles may come near this group's
     uint32_t *latch;    // slab mode: copy of the reduced rebuild word of the current step (flags + FLAG_LATCH)
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
@@ -112,10 +116,13 @@ enum {
     FLAG_NCHECK = 10,       // steps in which k_check ran
     FLAG_LATCH = 11,        // slab mode: the reduced rebuild word of this step, latched by k_halo_in for the final density pass
     FLAG_BAR_TIMEOUT = 12,  // k_rebuild: a grid barrier gave up waiting (its workgroups were not all resident)
-    FLAG_COUNT = 13
+    FLAG_WHY_DIRECT = 13,   // + k: tiles put on the direct path because of (k = 0) more column pairs than RMAX, (1) more rows between
+                            // the first and last own row than the bitmap holds, (2) more runs or cell-table entries than fit,
+                            // (3) more candidates than the LDS tile holds, (4) a window no byte can index, (5) a list longer than LROWS
+    FLAG_COUNT = 19
 };
 constexpr int TILE_WORDS = 32;           // 32-bit words per tile record
-constexpr int WNBR_WORDS = 10;           // words per box group in Arrays::wnbr
+constexpr int WNBR_WORDS = 12;           // words per box group in Arrays::wnbr
 #ifndef SPH_BOX_GROUP
 #define SPH_BOX_GROUP 64                 // consecutive sorted particles per displacement box (power of two, <= 64;
                                          // 16 / 32 / 64 measured the same rebuild rates on the dam break: one per wave)
@@ -125,8 +132,8 @@ constexpr int BOXG = SPH_BOX_GROUP;
 #define SPH_TILE_PARTICLES 256           // particles per tile (= threads per workgroup of the list kernels)
 #endif
 constexpr int LIST_WORDS_PER_TILE = 12 * SPH_TILE_PARTICLES;   // LROWS4 x TP (sph_list.inc static_asserts this)
-constexpr int XRANGE_WORDS = 100;                              // 3 RMAX + 1 prefix sums, 3 RMAX first particles (sph_list.inc)
-constexpr int STAB_ENTRIES_PER_TILE = 1280;                    // staging-table entries per tile (sph_list.inc)
+constexpr int XRANGE_WORDS = 260;                              // 4 RMAX + 1 prefix sums, 4 RMAX first particles (sph_list.inc)
+constexpr int STAB_ENTRIES_PER_TILE = 896;                     // staging-table entries per tile (sph_list.inc)
 constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle list padding points at (finite: no NaN)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record

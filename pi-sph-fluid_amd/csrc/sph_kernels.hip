@@ -55,6 +55,21 @@ DEV void cell_of_key(const Consts &c, uint32_t key, int &row, int &col) {
     row = (int)(key - (uint32_t)col * (uint32_t)c.rows);
 }
 
+// cell_start with out-of-grid cells reading as empty: an index below 0 (a column left of the grid) reads cell_start[0] = 0,
+// one beyond the grid (a column right of it) cell_start[n_cells] = n
+DEV uint32_t cs_ext(const uint32_t *__restrict__ cs, int cell, int n_cells) { return cs[min(max(cell, 0), n_cells)]; }
+// first sorted particle of cell (row, col); col may be -1 .. cols + 1 (empty columns), row 0 .. rows
+DEV uint32_t cs_at(const Consts &c, const uint32_t *__restrict__ cs, int col, int row) { return cs_ext(cs, col * c.rows + row, c.n_cells); }
+// Tile order.  The sorted arrays are column-major; the list kernels cut them into tiles TWO cell columns wide: columns
+// 2P ("A") and 2P + 1 ("B") form pair P, and the tile order runs through a pair row by row — cell (row, A), cell (row, B),
+// cell (row + 1, A) ... — then through the next pair.  Only the ORDER is virtual: a tile (256 consecutive particles of it)
+// is, per pair it touches, one contiguous range of column A and one of column B.  Rank of the first particle of pair-row
+// (P, row) in that order (equal to its index in the sorted arrays at the pair boundaries):
+DEV int n_pairs(const Consts &c) { return (c.cols + 1) >> 1; }
+DEV uint32_t tile_rank(const Consts &c, const uint32_t *__restrict__ cs, int pair, int row) {
+    return cs_at(c, cs, 2 * pair, row) + cs_at(c, cs, 2 * pair + 1, row) - cs_at(c, cs, 2 * pair + 1, 0);
+}
+
 // Wendland C2 without its normalising factor: (1 - q/2)^4 (1 + 2q), q = d/H   (:45-50)
 DEV float w_shape(const Consts &c, float d2) {
     float d = __builtin_amdgcn_sqrtf(d2);
@@ -109,41 +124,44 @@ DEV float group_max(float v) {
     return v;
 }
 // all 64 lanes of the wave must call this (live = the lane holds a particle this rank integrates: in slab mode the
-// boxes cover the owned particles only); slot = the lane's index in the sorted arrays
-DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int slot, float4 *__restrict__ wbox,
+// boxes cover the owned particles only); group = the wave's box group (tile * 4 + wave of the tile: sph_list.inc).  A group
+// without a live lane leaves an empty box (zero displacement): in slab mode k_check may look at it (see there).
+DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group, float4 *__restrict__ wbox,
                        uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild) {
+    static_assert(BOXG == 64, "a box group is a wave");
     const float d2 = fmaf(ux, ux, uy * uy);
     const bool over = live && !(d2 <= c.lim2);      // true for NaN too
     const bool capped = live && !(d2 <= c.cap2);
     const float inf = __builtin_huge_valf();
     const float x0 = group_min(live ? ux : inf), y0 = group_min(live ? uy : inf);
     const float x1 = group_max(live ? ux : -inf), y1 = group_max(live ? uy : -inf);
-    const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped);
-    // the first live lane of each group writes its box (slab mode: the owned range may begin or end inside a group)
-    const int lane = threadIdx.x & 63;
-    const unsigned long long group = (BOXG == 64 ? ~0ull : ((1ull << (BOXG & 63)) - 1ull) << (lane & ~(BOXG - 1))) & __ballot(live);
-    if (group != 0ull && lane == (int)__builtin_ctzll(group)) wbox[slot / BOXG] = make_float4(x0, y0, x1, y1);
+    const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped), any_live = __ballot(live);
     if ((threadIdx.x & 63) == 0) {
+        wbox[group] = any_live != 0ull ? make_float4(x0, y0, x1, y1) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (any_over != 0ull) *check = 1u;
         if (any_cap != 0ull) *rebuild = 1u;
     }
 }
 
-// kick 1/2 + drift in place (:615-624), 48 B/particle: the stand-alone form (slab mode; single GPU: the first step
-// after creation / upload — afterwards the force pass does this for the next step, sph_list.inc).
+// kick 1/2 + drift in place (:615-624), 48 B/particle: the stand-alone form (the first step after creation / upload —
+// afterwards the force pass does this for the next step, sph_list.inc).  One thread per tile lane (lrec: the lane's
+// particle), so that a wave is one box group here as in the force pass.
 template <bool SLAB>
 __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict__ pos, const float2 *__restrict__ pos_ref,
                                                     const float2 *__restrict__ acc, const float2 *__restrict__ velt,
                                                     float2 *__restrict__ vel, const uint32_t *__restrict__ cs,
-                                                    float4 *__restrict__ wbox, uint32_t *__restrict__ check,
-                                                    uint32_t *__restrict__ rebuild, const uint32_t *__restrict__ dn) {
+                                                    const uint2 *__restrict__ lrec, float4 *__restrict__ wbox,
+                                                    uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild,
+                                                    const uint32_t *__restrict__ dn) {
     // slab mode: only the OWNED range of the sorted arrays moves (cell_start of the last rebuild); the ghosts are
-    // refreshed from their owners by the halo exchange of this step.  One thread per array slot, so that a wave is
-    // one box group here as in the force pass.
+    // refreshed from their owners by the halo exchange of this step
+    const int n = (int)dn[0];
     const int own_lo = SLAB ? (int)cs[c.ghost * c.rows] : 0;
-    const int own_hi = SLAB ? (int)cs[(c.ghost + c.owned) * c.rows] : (int)dn[0];
-    const int i = blockIdx.x * BLK + threadIdx.x;
-    const bool live = i >= own_lo && i < own_hi;
+    const int own_hi = SLAB ? (int)cs[(c.ghost + c.owned) * c.rows] : n;
+    const int t = blockIdx.x * BLK + threadIdx.x;      // rank in the tile order
+    if ((int)(blockIdx.x * BLK) >= n) return;          // whole workgroup beyond the live count
+    const int i = t < n ? (int)lrec[t].x : n;
+    const bool live = t < n && i >= own_lo && i < own_hi;
     float ux = 0.0f, uy = 0.0f;
     if (live) {
         const float2 a = acc[i], r = pos_ref[i];
@@ -157,14 +175,14 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
         ux = p.x - r.x;
         uy = p.y - r.y;
     }
-    drift_verdict(c, ux, uy, live, i, wbox, check, rebuild);
+    drift_verdict(c, ux, uy, live, t / BOXG, wbox, check, rebuild);
 }
 
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab) {
     if (cap <= 0) return;
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
-    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.wbox, a.check, a.rebuild, a.dn);
-    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.wbox, a.check, a.rebuild, a.dn);
+    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn);
+    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -281,10 +299,10 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
 }
 
 // the pair part of criterion (1): every box group against every group k_build_list listed for it, eight threads per group
-// (one per column range, three idle: the loads of a group are a chain of dependent latencies when one thread does them all)
+// (one per range of groups, two idle: the loads of a group are a chain of dependent latencies when one thread does them all)
 constexpr int CHECK_LANES = 8;
 DEV void check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr, uint32_t *__restrict__ rebuild,
-                     const int w, const int k, const int own_lo, const int own_hi);
+                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe);
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                                                const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
                                                uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
@@ -298,31 +316,42 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
     if (*check == 0u) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
     const int n = (int)dn[0];
-    // the slots this rank integrates (single GPU: all of them)
-    const int own_lo = c.ghost ? (int)cs[c.ghost * c.rows] : 0, own_hi = c.ghost ? (int)cs[(c.ghost + c.owned) * c.rows] : n;
+    // The ranks (tile order, see tile_rank) this rank integrates; single GPU: all of them.  A slab's owned columns begin
+    // at a pair boundary (two ghost columns); they end at one when their number is even.  Otherwise the last owned column
+    // shares its pair with the first ghost column, and the ranks of that pair are a mix: own_hi = the end of that pair
+    // (every group that holds an owned particle lies below it), own_safe = its beginning (a group whose neighbourhood
+    // stays below it meets owned particles only).
+    int own_lo = 0, own_hi = n, own_safe = n;
+    if (c.ghost) {
+        own_lo = (int)cs[c.ghost * c.rows];
+        own_hi = (int)cs_ext(cs, (c.ghost + c.owned + (c.owned & 1)) * c.rows, c.n_cells);
+        own_safe = (int)cs[(c.ghost + c.owned - (c.owned & 1)) * c.rows];
+    }
     // (a small grid striding over the groups: see k_key_hist)
-    for (int t = blockIdx.x * BLK + threadIdx.x; t < nw * CHECK_LANES; t += gridDim.x * BLK) check_group(c, wbox, wnbr, rebuild, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi);
+    for (int t = blockIdx.x * BLK + threadIdx.x; t < nw * CHECK_LANES; t += gridDim.x * BLK)
+        check_group(c, wbox, wnbr, rebuild, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi, own_safe);
 }
 DEV void check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr, uint32_t *__restrict__ rebuild,
-                     const int w, const int k, const int own_lo, const int own_hi) {
-    if (w * BOXG >= own_hi || (w + 1) * BOXG <= own_lo) return;      // no owned particle in this group: no box
+                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe) {
+    if (w * BOXG >= own_hi || (w + 1) * BOXG <= own_lo) return;      // no owned particle in this group
     const float4 b = wbox[w];
     const uint32_t *nb = wnbr + (size_t)w * WNBR_WORDS;
     bool meets_ghosts = false;
     if (c.ghost) {
+        meets_ghosts = w * BOXG < own_lo || (w + 1) * BOXG > own_safe;
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
+        for (int j = 0; j < WNBR_WORDS / 2; j++) {
             const uint32_t first = nb[2 * j], last = nb[2 * j + 1];
-            if (first <= last) meets_ghosts |= (int)(first * BOXG) < own_lo || (int)((last + 1u) * BOXG) > own_hi;
+            if (first <= last) meets_ghosts |= (int)(first * BOXG) < own_lo || (int)((last + 1u) * BOXG) > own_safe;
         }
     }
     bool bad = false;
     if (meets_ghosts) {
         const float mx = fmaxf(fabsf(b.x), fabsf(b.z)), my = fmaxf(fabsf(b.y), fabsf(b.w));
         bad = k == 0 && !(fmaf(mx, mx, my * my) <= c.lim2);
-    } else if (k < 5) {
+    } else if (k < WNBR_WORDS / 2) {
         const uint32_t first = nb[2 * k], last = nb[2 * k + 1];
-        for (uint32_t o = first; o <= last && o != 0xffffffffu; o++) {      // first > last: nobody in that column
+        for (uint32_t o = first; o <= last && o != 0xffffffffu; o++) {      // first > last: nobody in that pair
             const float4 q = wbox[o];
             const float rx = fmaxf(b.z - q.x, q.z - b.x), ry = fmaxf(b.w - q.y, q.w - b.y);
             bad |= !(fmaf(rx, rx, ry * ry) <= c.skin2);
@@ -697,16 +726,43 @@ DEV void reorder_body(const float4 *__restrict__ pk, const float2 *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(BLK) void k_reorder(const float4 *__restrict__ pk, const float2 *__restrict__ velk,
+// Where the tiles of the list kernels begin (tile order: tile_rank).  One thread per pair-row: the pair-row in which rank
+// 256 T falls records, for tile T, {pair, row, index in column A, index in column B} of the tile's first particle (the
+// particles of a pair-row count in the order cell A, cell B); the tile ends where tile T + 1 begins.  Also per pair: the
+// first and the last row that hold particles.  Part of the scatter phase of a rebuild: it reads cell_start only.
+DEV void tile_starts_body(const Consts &c, const uint32_t *__restrict__ cs, uint32_t *__restrict__ tstart, uint32_t *__restrict__ pext,
+                          const int n) {
+    const int np = n_pairs(c), total = np * c.rows;
+    for (int t = blockIdx.x * BLK + threadIdx.x; t < total; t += gridDim.x * BLK) {
+        const int P = t / c.rows, r = t - P * c.rows;
+        const uint32_t a0 = cs_at(c, cs, 2 * P, r), a1 = cs_at(c, cs, 2 * P, r + 1);
+        const uint32_t b0 = cs_at(c, cs, 2 * P + 1, r), b1 = cs_at(c, cs, 2 * P + 1, r + 1);
+        if (a1 + b1 == a0 + b0) continue;                      // nobody in this pair-row
+        const uint32_t base_a = cs_at(c, cs, 2 * P, 0), base_b = cs_at(c, cs, 2 * P + 1, 0), end = cs_at(c, cs, 2 * P + 2, 0);
+        if (a0 == base_a && b0 == base_b) pext[2 * P] = (uint32_t)r;
+        if (a1 == base_b && b1 == end) pext[2 * P + 1] = (uint32_t)r;
+        const uint32_t m0 = a0 + b0 - base_b, m1 = a1 + b1 - base_b, ca = a1 - a0;      // ranks [m0, m1)
+        if (m1 == (uint32_t)n)      // the last pair-row that holds anybody: the last tile ends behind this pair
+            reinterpret_cast<uint4 *>(tstart)[(n + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES] = make_uint4((uint32_t)P + 1u, 0u, (uint32_t)n, (uint32_t)n);
+        for (uint32_t T = (m0 + (uint32_t)SPH_TILE_PARTICLES - 1u) / (uint32_t)SPH_TILE_PARTICLES; T * (uint32_t)SPH_TILE_PARTICLES < m1; T++) {
+            const uint32_t o = T * (uint32_t)SPH_TILE_PARTICLES - m0;
+            reinterpret_cast<uint4 *>(tstart)[T] = make_uint4((uint32_t)P, (uint32_t)r, o < ca ? a0 + o : a1, o < ca ? b0 : b0 + (o - ca));
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_reorder(Consts c, const float4 *__restrict__ pk, const float2 *__restrict__ velk,
                                                  const uint32_t *__restrict__ slot,
                                                  const uint32_t *__restrict__ cell_start, float2 *__restrict__ pos,
                                                  float2 *__restrict__ pos_ref, float2 *__restrict__ vel,
                                                  uint32_t *__restrict__ id, uint32_t *__restrict__ skey,
                                                  const uint32_t *__restrict__ dn, const uint32_t *__restrict__ rebuild,
                                                  uint32_t *__restrict__ block_sums, int scan_tiles,
-                                                 const uint32_t *__restrict__ cell_ids) {
+                                                 const uint32_t *__restrict__ cell_ids, uint32_t *__restrict__ tstart,
+                                                 uint32_t *__restrict__ pext) {
     if (*rebuild == 0u) return;
     reorder_body(pk, velk, slot, cell_start, pos, pos_ref, vel, id, skey, (int)dn[0], block_sums, scan_tiles, cell_ids);
+    tile_starts_body(c, cell_start, tstart, pext, (int)dn[0]);
 }
 
 void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool deterministic) {
@@ -715,8 +771,8 @@ void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap, b
     uint32_t *cell_ids = deterministic ? a.nlist : nullptr;      // (the lists are rebuilt after the scatter: free until then)
     if (deterministic)
         hipLaunchKernelGGL(k_cell_ids, dim3(gated_grid((cap + BLK - 1) / BLK)), dim3(BLK), 0, st, a.pk, a.slot, a.cell_start, cell_ids, a.dn, a.rebuild);
-    hipLaunchKernelGGL(k_reorder, dim3(gated_grid((cap + BLK - 1) / BLK)), dim3(BLK), 0, st, a.pk, a.velk, a.slot, a.cell_start, a.pos,
-                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.rebuild, a.block_sums, scan_tiles, cell_ids);
+    hipLaunchKernelGGL(k_reorder, dim3(gated_grid((cap + BLK - 1) / BLK)), dim3(BLK), 0, st, c, a.pk, a.velk, a.slot, a.cell_start, a.pos,
+                       a.pos_ref, a.vel, a.id, a.skey, a.dn, a.rebuild, a.block_sums, scan_tiles, cell_ids, a.tstart, a.pext);
 }
 
 // ------------------------------------------------------------------------------------------

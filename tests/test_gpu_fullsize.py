@@ -98,6 +98,14 @@ def test_fullsize_scene_vs_oracle(sph, orc, oracle, name, warm):
         sdu, sdv = ctx.read_accel()
         assert np.max(np.hypot(sdu - odu, sdv - odv) / (sa + G)) <= TOL           # G3
         _, direct2 = ctx.rebuild_stats()
+        # Tiles on the direct (no list) path hold their kernels back.  The dam break and the falling drop must have none;
+        # in the splash of the drop (|v| to 100 m/s, spray over hundreds of cell rows) a tile of 256 droplets may span more
+        # rows than the list build's tables hold: that — and only that — is allowed, a fraction of a tile per rebuild
+        why = ctx.direct_tile_reasons()
+        if name == "cfg2" or warm == 0:
+            assert direct2 == 0, (direct2, why)
+        else:
+            assert direct2 <= 0.5 * rebuilds and why[3] == 0 and why[4] == 0 and why[5] == 0, (direct2, rebuilds, why)
 
         # ---- exact walk (variant 1) on the same state ----
         ctx.set_variant(1)
