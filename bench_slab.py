@@ -118,6 +118,8 @@ def run_slabs(sph, args, emit):
     slab = sph.slab.GpuSlab(sph, prm, None, walls, c0, c1, rank > 0, rank < world - 1, g0[0], g0[1], device=device,
                             local=(loc, ids))
     del loc, ids
+    one_launch = not host_staged      # one rank per GPU: nothing else computes on the device (sph_set_rebuild_launches)
+    slab.set_rebuild_launches(one_launch)
     dt_sim = float(np.float32(prm.dt))
     stream = torch.cuda.Stream(device=device)
     sim_step = [0]
@@ -132,7 +134,9 @@ def run_slabs(sph, args, emit):
         transport = (HostStagedTransport(torch, dist, slab, rank, world) if host_staged
                      else sph.slab.TorchTransport(torch, dist, slab, rank, world, torch.device("cuda", device)))
         def factory(a, z, hl, hr, loc_, ids_, gx_, gy_):
-            return sph.slab.GpuSlab(sph, prm, None, walls, a, z, hl, hr, gx_, gy_, device=device, local=(loc_, ids_))
+            new = sph.slab.GpuSlab(sph, prm, None, walls, a, z, hl, hr, gx_, gy_, device=device, local=(loc_, ids_))
+            new.set_rebuild_launches(one_launch)
+            return new
 
         runner = sph.slab.SlabRunner(slab, transport, factory=factory, prm=prm, rank0=rank, world=world)
         log(rank, "slab columns [%d,%d) of %d created in %.2fs, local/owned = %s" %

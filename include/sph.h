@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 4
+#define SPH_ABI_VERSION 5
 
 typedef enum sph_error {
     SPH_OK = 0,
@@ -140,7 +140,8 @@ int  sph_update_boundary(sph_ctx *ctx, const sph_particle *boundary);
  * (sph_update_boundary moves walls); nothing is re-binned or rebuilt, so this is cheap enough for every step, e.g. with
  * the velocity a host infers from its accelerometer (sph_wall_motion, include/sph_host.h; README.md:175-176). */
 int  sph_set_boundary_velocity(sph_ctx *ctx, float u, float v);
-/* the statistics of :657-671 as device reductions: max rho and max sqrt(u^2+v^2) over fluid */
+/* the statistics of :657-671 as device reductions: max rho and max sqrt(u^2+v^2) over fluid (a slab context: over the
+ * particles it owns; the host takes the maximum over the ranks) */
 int  sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed);
 
 int  sph_n_fluid(const sph_ctx *ctx);
@@ -170,8 +171,9 @@ int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_til
 /* why list builds put tiles on the direct path so far, as counts: [0] the tile touches more column pairs than the build's
  * tables hold, [1] more rows between its first and last particle than its row bitmap, [2] more runs of rows or cell-table
  * entries, [3] more candidates than the LDS tile, [4] a candidate window longer than a list byte can index, [5] a
- * neighbour list longer than the list capacity (measurement / diagnostics) */
-int   sph_direct_tile_reasons(sph_ctx *ctx, long long why[6]);
+ * neighbour list longer than the list capacity; and [6] workgroups of one-launch rebuilds that did not run on the XCD of
+ * their grid-barrier leader and took the slow path (measurement / diagnostics) */
+int   sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]);
 /* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
 int   sph_check_stats(sph_ctx *ctx, long long *checks);
 /* total particles clamped into the domain so far (0 in a healthy run) */
@@ -211,10 +213,14 @@ int  sph_set_variant(sph_ctx *ctx, int variant);
  * that rebuild nothing pay for one empty launch instead of four.  It needs the device to itself: sph_create tries its
  * barriers once and falls back to one kernel per phase where they do not complete (compute units masked off or held
  * by another process); should that happen later, a barrier gives up after a few seconds and the next call that checks
- * the flags returns SPH_E_STATE.  one_launch = 0: one kernel per phase (what a context does anyway while
- * another context of the same process lives on its device: several slabs on one GPU, A/B comparisons).  Slab contexts
- * do the same with what follows their halo exchange (ghost update / ingest, scan, scatter, canonical order, lists).
- * Results are the same either way. */
+ * the flags returns SPH_E_STATE.  one_launch = 0: one kernel per phase (what a single-GPU context does anyway while
+ * another context of the same process lives on its device: A/B comparisons).
+ * Slab contexts do the same with what follows their halo exchange (ghost update / ingest, scan, scatter, canonical
+ * order, lists), but only when their host asks for it (default: one kernel per phase): several slabs may share a device,
+ * in one process or in several, and the library cannot see the other processes.  A host that calls this with
+ * one_launch = 1 on a slab context vouches that nothing else computes on that device while the slab steps: one rank per
+ * GPU (the C multi-GPU host over RCCL does), or slabs of one device stepped strictly one after the other with a
+ * synchronisation in between.  Results are the same either way. */
 int  sph_set_rebuild_launches(sph_ctx *ctx, int one_launch);
 int  sph_get_rebuild_launches(const sph_ctx *ctx);      /* 1: one launch, 0: one kernel per phase (as of the last step) */
 
@@ -264,12 +270,17 @@ int  sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void 
 /* host-staged transport (tests, non-RCCL hosts): side 0 = left, 1 = right */
 int  sph_slab_copy_out(sph_ctx *ctx, int side, void *host_bytes);
 int  sph_slab_copy_in(sph_ctx *ctx, int side, const void *host_bytes);
+/* bytes of one halo buffer of a slab created with these parameters and this halo_capacity (0 = default): what a host
+ * needs to know before it creates the context (shared-memory transports size their mailboxes with it) */
+size_t sph_slab_halo_bytes(const sph_params *prm, int halo_capacity);
 /* owned particles (any order) with their global ids and accelerations; *n_out = owned count */
 int  sph_slab_read(sph_ctx *ctx, sph_particle *out, uint32_t *ids, float *du_dt, float *dv_dt, int cap, int *n_out);
 int  sph_slab_counts(sph_ctx *ctx, int *n_local, int *n_owned);
 
 /* ---- metaball renderer (next row f1): draw_metaballs :380-411 + pixel grid :570-577 ----
- * 128 x 64 1-bpp SSD1306 page-format bitmap, 1024 bytes: bit (i%8) of byte (i/8)*128+j. */
+ * 128 x 64 1-bpp SSD1306 page-format bitmap, 1024 bytes: bit (i%8) of byte (i/8)*128+j.
+ * A slab context renders the pixels whose centres lie in the cell columns it owns and leaves the others 0: the bitwise
+ * OR of the pages of all slabs is the frame (1 KB per rank crosses PCIe; an 8-bit OR all-reduce or a host OR joins them). */
 int  sph_render_metaballs(sph_ctx *ctx, unsigned char *draw_buffer_1024);
 
 #ifdef __cplusplus

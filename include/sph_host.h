@@ -59,6 +59,9 @@ int  sph_slab_column_of(const sph_params *prm, float x);
  * with ~equal particle counts (quantiles of the per-column histogram), every range at least 4 columns, the first
  * beginning at column 0 and the last ending at the box edge (a dam-break front never leaves the decomposition). */
 int  sph_slab_partition_block(const sph_params *prm, float x0, long nx, long ny, int world, int *cuts);
+/* the same cuts from a per-column particle histogram hist[0..cols) (re-balancing: the histogram of the current state,
+ * summed over the ranks) */
+int  sph_slab_partition_counts(const long long *hist, int cols, int world, int *cuts);
 /* lattice columns [i_begin, i_end) of the block that lie in cell columns [col_begin - 2, col_end + 2): what the rank
  * owning [col_begin, col_end) generates (sph_scene_block_range); global id of its k-th particle = i_begin * ny + k */
 int  sph_slab_block_columns(const sph_params *prm, float x0, long nx, int col_begin, int col_end, long *i_begin, long *i_end);

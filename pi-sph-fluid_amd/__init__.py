@@ -45,13 +45,13 @@ ABI_SYMBOLS = [
     "sph_render_metaballs",
     "sph_create_slab", "sph_slab_step_begin", "sph_slab_step_pack", "sph_slab_step_overlap", "sph_slab_step_end",
     "sph_slab_flag_buffer", "sph_slab_set_flag_buffer", "sph_slab_flag_get", "sph_slab_flag_set", "sph_slab_buffers", "sph_slab_set_buffers",
-    "sph_slab_copy_out", "sph_slab_copy_in", "sph_slab_read", "sph_slab_counts",
+    "sph_slab_copy_out", "sph_slab_copy_in", "sph_slab_read", "sph_slab_counts", "sph_slab_halo_bytes",
 ]
 HOST_SYMBOLS = [
     "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",
     "sph_scene_block_range", "sph_scene_walls_layers",
     "sph_gravity_init", "sph_gravity_sample", "sph_wall_motion_init", "sph_wall_motion_update",
-    "sph_slab_grid_columns", "sph_slab_column_of", "sph_slab_partition_block", "sph_slab_block_columns",
+    "sph_slab_grid_columns", "sph_slab_column_of", "sph_slab_partition_block", "sph_slab_partition_counts", "sph_slab_block_columns",
 ]
 
 
@@ -156,6 +156,8 @@ def hip_lib():
         L.sph_device_bytes.restype = C.c_size_t
         L.sph_set_variant.argtypes = [vp, ci]
         L.sph_render_metaballs.argtypes = [vp, vp]
+        L.sph_slab_halo_bytes.argtypes = [C.POINTER(Params), ci]
+        L.sph_slab_halo_bytes.restype = C.c_size_t
         L.sph_create_slab.argtypes = [C.POINTER(vp), C.POINTER(Params), C.POINTER(SlabDesc), vp, vp, ci, vp, ci, cf, cf, ci]
         L.sph_slab_step_begin.argtypes = [vp, cf, cf]
         L.sph_slab_step_pack.argtypes = [vp]
@@ -199,6 +201,7 @@ def host_lib():
         L.sph_slab_column_of.argtypes = [C.POINTER(Params), cf]
         L.sph_slab_partition_block.argtypes = [C.POINTER(Params), cf, cl, cl, C.c_int, C.POINTER(C.c_int)]
         L.sph_slab_block_columns.argtypes = [C.POINTER(Params), cf, cl, C.c_int, C.c_int, C.POINTER(cl), C.POINTER(cl)]
+        L.sph_slab_partition_counts.argtypes = [C.POINTER(C.c_longlong), C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.sph_gravity_init.argtypes = [C.POINTER(Gravity), C.c_int, cf]
         L.sph_gravity_init.restype = None
         L.sph_gravity_sample.argtypes = [C.POINTER(Gravity), cf, C.POINTER(cf), C.POINTER(cf)]
@@ -449,7 +452,7 @@ class Context:
 
     def direct_tile_reasons(self):
         """why tiles went to the direct path so far: counts of (pairs, rows, runs / cell table, candidates, window, list length)."""
-        a = (C.c_longlong * 6)()
+        a = (C.c_longlong * 7)()
         self._chk(self.L.sph_direct_tile_reasons(self.h, a))
         return tuple(int(x) for x in a)
 

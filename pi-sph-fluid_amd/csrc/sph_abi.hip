@@ -58,6 +58,7 @@ struct sph_ctx {
     hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
+    bool one_launch_asked = false;  // sph_set_rebuild_launches(ctx, 1): the host vouches that nothing else computes on the device meanwhile
     bool counted = false;        // this context is in g_live_contexts
     bool deterministic = false;  // particles of a cell in id order (sph_set_deterministic)
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
@@ -327,7 +328,8 @@ int check_flags(sph_ctx *ctx) {
 // The one-launch rebuild needs all its workgroups resident at once.  Try its barriers once, now: where they do not
 // complete (compute units masked off or held by somebody else), this context rebuilds with one kernel per phase.
 int selftest_one_launch(sph_ctx *ctx) {
-    if (ctx->rebuild_wgs <= 0 || device_shared(ctx)) return SPH_OK;      // (in company the context does not use it: sph_step)
+    // (in company a single-GPU context does not use it: sph_step; a slab context uses it because its host said so)
+    if (ctx->rebuild_wgs <= 0 || (device_shared(ctx) && !(ctx->slab && ctx->one_launch_asked))) return SPH_OK;
     hipStream_t st = ctx->stream;
     launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, true);
     uint32_t timed_out = 0;
@@ -468,7 +470,9 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         g_live_contexts[ctx->device].fetch_add(1);
         ctx->counted = true;
     }
-    ctx->rebuild_wgs = rebuild_grid(ctx->device, ctx->cap);
+    // one launch for the rebuild chain: single-GPU contexts by default; a slab context only when its host asks for it
+    // (sph_set_rebuild_launches): several slabs may share a device, in one process or in several
+    ctx->rebuild_wgs = slab ? 0 : rebuild_grid(ctx->device, ctx->cap);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
@@ -580,7 +584,7 @@ int sph_create_slab(sph_ctx **out, const sph_params *prm, const sph_slab_desc *d
     sp.col_end = desc->col_end;
     sp.has_left = desc->has_left != 0;
     sp.has_right = desc->has_right != 0;
-    sp.halo_cap = desc->halo_capacity > 0 ? desc->halo_capacity : 4 * cg.rows * 16;
+    sp.halo_cap = desc->halo_capacity > 0 ? desc->halo_capacity : 4 * cg.rows * 16;      // (sph_slab_halo_bytes says the same)
     sp.particle_cap = desc->particle_capacity > 0 ? desc->particle_capacity : n_fluid + n_fluid / 4 + 2 * sp.halo_cap + 1024;
     return init_context(ctx, prm, fluid, ids, n_fluid, bloc.data(), (int)bloc.size(), true, gx, gy, device, &sp);
 }
@@ -700,7 +704,7 @@ int sph_stats(sph_ctx *ctx, float *max_rho, float *max_speed) {
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_MAXRHO, 0, 2 * sizeof(uint32_t), ctx->stream));
     refresh_velt(ctx);
-    launch_stats(ctx->stream, ctx->a, ctx->n);
+    launch_stats(ctx->stream, ctx->c, ctx->a, ctx->slab ? ctx->cap : ctx->n, ctx->slab);      // (a slab: its owned particles)
     uint32_t h[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags + FLAG_MAXRHO, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -752,13 +756,14 @@ int sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles
     if (direct_tiles) *direct_tiles = h[FLAG_DIRECT_TILES];
     return SPH_OK;
 }
-int sph_direct_tile_reasons(sph_ctx *ctx, long long why[6]) {
+int sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]) {
     if (!ctx || !ctx->stream || !why) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
-    uint32_t h[6] = {0};
+    uint32_t h[7] = {0};
+    static_assert(FLAG_OFF_XCD == FLAG_WHY_DIRECT + 6, "the diagnostics are read as one block");
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags + FLAG_WHY_DIRECT, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 6; k++) why[k] = h[k];
+    for (int k = 0; k < 7; k++) why[k] = h[k];
     return SPH_OK;
 }
 int sph_check_stats(sph_ctx *ctx, long long *checks) {
@@ -782,6 +787,7 @@ int sph_set_rebuild_launches(sph_ctx *ctx, int one_launch) {
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     drop_graph(ctx);
+    ctx->one_launch_asked = one_launch != 0;
     ctx->rebuild_wgs = one_launch ? rebuild_grid(ctx->device, ctx->cap) : 0;
     if (one_launch && ctx->rebuild_wgs <= 0) return fail(ctx, SPH_E_HIP, "occupancy query for the one-launch rebuild failed");
     if (one_launch) {
@@ -1009,7 +1015,7 @@ int sph_slab_step_end(sph_ctx *ctx) {
     if (!ctx->slab || ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_pack");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    if (ctx->rebuild_wgs > 0 && !device_shared(ctx)) {      // alone on the device: one launch (see g_live_contexts)
+    if (ctx->rebuild_wgs > 0) {      // the host asked for it (sph_set_rebuild_launches): nothing else computes on the device meanwhile
         launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic);
     } else {
         launch_halo_in(st, ctx->c, ctx->a, ctx->cap);               // rebuild step: ingest (then the next four); else ghost update
@@ -1026,6 +1032,13 @@ int sph_slab_step_end(sph_ctx *ctx) {
     ctx->slab_overlapped = false;
     ctx->slab_phase = 0;
     return SPH_OK;
+}
+
+size_t sph_slab_halo_bytes(const sph_params *prm, int halo_capacity) {
+    Consts cg;
+    if (!prm || make_consts(*prm, cg) != SPH_OK) return 0;
+    const size_t cap = halo_capacity > 0 ? (size_t)halo_capacity : (size_t)4 * cg.rows * 16;      // the default of sph_create_slab
+    return sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * cap);
 }
 
 int sph_slab_flag_buffer(sph_ctx *ctx, void **dev_word) {
@@ -1146,7 +1159,7 @@ int sph_slab_counts(sph_ctx *ctx, int *n_local, int *n_owned) {
 // ---- metaballs (next row f1) ----
 int sph_render_metaballs(sph_ctx *ctx, unsigned char *draw_buffer) {
     if (!ctx || !ctx->stream || !draw_buffer) return SPH_E_ARG;
-    if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_render_metaballs is single-GPU only");
+    if (ctx->slab && ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_render_metaballs mid-step");
     (void)hipSetDevice(ctx->device);
     // the kernel emits the SSD1306 page format itself (:407-408): 1 KB crosses PCIe, straight into the caller's buffer
     launch_metaballs(ctx->stream, ctx->c, ctx->a, ctx->prm.x_max - ctx->prm.x_min, ctx->prm.y_max - ctx->prm.y_min,

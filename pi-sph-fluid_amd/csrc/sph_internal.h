@@ -119,7 +119,8 @@ enum {
     FLAG_WHY_DIRECT = 13,   // + k: tiles put on the direct path because of (k = 0) more column pairs than RMAX, (1) more rows between
                             // the first and last own row than the bitmap holds, (2) more runs or cell-table entries than fit,
                             // (3) more candidates than the LDS tile holds, (4) a window no byte can index, (5) a list longer than LROWS
-    FLAG_COUNT = 19
+    FLAG_OFF_XCD = 19,      // workgroups of one-launch rebuilds so far that did not run on the XCD of their barrier leader
+    FLAG_COUNT = 20
 };
 constexpr int TILE_WORDS = 32;           // 32-bit words per tile record
 constexpr int WNBR_WORDS = 12;           // words per box group in Arrays::wnbr
@@ -221,7 +222,7 @@ void launch_gather_accel(hipStream_t st, const Arrays &a, int n, const float *du
 void launch_unsort_boundary(hipStream_t st, const Consts &c, const Arrays &a, int nb, sph_particle *out_dev);
 void launch_upload_state(hipStream_t st, const Arrays &a, int n, const sph_particle *in_dev);
 void launch_gather_rho_p(hipStream_t st, const Consts &c, const Arrays &a, int n, const sph_particle *in_dev);
-void launch_stats(hipStream_t st, const Arrays &a, int n);
+void launch_stats(hipStream_t st, const Consts &c, const Arrays &a, int n, bool slab);
 // velt := vel + dt/2 acc (the velocity between steps, which the fused force pass does not store)
 void launch_refresh_velt(hipStream_t st, const Consts &c, const Arrays &a, int cap);
 void launch_metaballs(hipStream_t st, const Consts &c, const Arrays &a, float width, float height,

@@ -1238,10 +1238,12 @@ void launch_refresh_velt(hipStream_t st, const Consts &c, const Arrays &a, int c
 
 // ------------------------------------------------------------------------------------------
 // statistics of :657-671 as device max-reductions (non-negative floats order like their bit patterns)
-__global__ __launch_bounds__(BLK) void k_stats(const float2 *__restrict__ rp, const float2 *__restrict__ velt,
-                                               uint32_t *__restrict__ flags, int n) {
+// slab: the owned range of the sorted arrays only (the ghosts belong to the neighbours' statistics)
+__global__ __launch_bounds__(BLK) void k_stats(Consts c, const float2 *__restrict__ rp, const float2 *__restrict__ velt,
+                                               const uint32_t *__restrict__ cs, uint32_t *__restrict__ flags, int n, int slab) {
     float mr = 0.0f, ms = 0.0f;
-    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+    const int lo = slab ? (int)cs[c.ghost * c.rows] : 0, hi = slab ? (int)cs[(c.ghost + c.owned) * c.rows] : n;
+    for (int i = lo + blockIdx.x * BLK + threadIdx.x; i < hi; i += gridDim.x * BLK) {
         mr = fmaxf(mr, rp[i].x);
         float2 v = velt[i];
         ms = fmaxf(ms, fmaf(v.x, v.x, v.y * v.y));
@@ -1256,10 +1258,10 @@ __global__ __launch_bounds__(BLK) void k_stats(const float2 *__restrict__ rp, co
         atomicMax(&flags[FLAG_MAXSPEED], __float_as_uint(sqrtf(ms)));
     }
 }
-void launch_stats(hipStream_t st, const Arrays &a, int n) {
+void launch_stats(hipStream_t st, const Consts &c, const Arrays &a, int n, bool slab) {
     if (n <= 0) return;
     int blocks = min((n + BLK - 1) / BLK, 2048);
-    hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(BLK), 0, st, a.rp, a.velt, a.flags, n);
+    hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(BLK), 0, st, c, a.rp, a.velt, a.cell_start, a.flags, n, slab ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1277,10 +1279,13 @@ __global__ __launch_bounds__(BLK) void k_metaballs(Consts c, const float2 *__res
     int row, col;
     bool oob, bad;
     cell_of(c, px, py, row, col, oob, bad);
+    // slab mode: a slab renders the pixels whose centres lie in its owned columns (every pixel belongs to exactly one slab;
+    // the host ORs the pages); the two ghost columns per side are what the 5x5 walk below needs
+    const bool mine = c.ghost == 0 || (!oob && col >= c.ghost && col < c.ghost + c.owned);
     // 5x5 sort cells: a particle may be up to H + skin from where it was sorted (see drift_verdict)
     int r0 = max(row - 2, 0), r1 = min(row + 2, c.rows - 1);
     float s = 0.0f;
-    for (int cc = max(col - 2, 0); cc <= min(col + 2, c.cols - 1); cc++) {
+    for (int cc = max(col - 2, 0); mine && cc <= min(col + 2, c.cols - 1); cc++) {
         int base = cc * c.rows;
         uint32_t beg = cs[base + r0], end = cs[base + r1 + 1];
         for (uint32_t k = beg; k < end; k++) {

@@ -4,19 +4,30 @@
  * The reference (pi_sph_fluid.c) has no distributed path: its particle loops (:272, :311) run on one node.  This host
  * shards them by cell column and drives the slab entry points of include/sph.h; per step and rank
  *     sph_slab_step_begin     kick 1/2 + drift of the owned particles (:615-624), may raise the rebuild word
- *     ncclAllReduce(max)      on the device word itself (sph_slab_flag_buffer): all slabs rebuild in the same step
+ *     MAX-reduce the word     over all ranks: all slabs rebuild in the same step
  *     sph_slab_step_pack      fills the send buffers (full records on a rebuild step, x/y/u/v updates otherwise)
- *     ncclGroupStart; ncclSend / ncclRecv with each neighbour; ncclGroupEnd        (sph_slab_buffers, device memory)
- *     sph_slab_step_overlap   density of the tiles that stage no ghost particle, enqueued behind the sends on the same
- *                             stream only when there is no neighbour; with neighbours the exchange runs on a second
- *                             stream and this runs beside it
+ *     exchange                send_right -> right neighbour's recv_left, send_left -> left neighbour's recv_right
+ *     sph_slab_step_overlap   density of the tiles that stage no ghost particle, beside the exchange
  *     sph_slab_step_end       ingest + sort + lists | ghost update, density of the rest, force + kick (:626-640)
- * Everything is enqueued on HIP streams; the host synchronises only around the timed region.
+ * and, every 0.1 s of simulated time, the reference's console line (:679-691: ticks/s, max rho error, max speed — the two
+ * maxima reduced over the ranks); every K steps (--rebalance-every K) new column ranges from the current per-column
+ * particle histogram, the particles shipped to the slabs that now hold their columns, the slab contexts re-created.
  *
- *   slab_sph_fluid --ranks N [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--steps K] [--warmup W] [--tilt]
- *                  [--check] [--deterministic] [--skin F]
- * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device r.
- * The ncclUniqueId travels through a file (--id-file, made by the launcher).  --scene dam: N lattice blocks of
+ * Transports (--transport):
+ *   rccl  (default) ncclAllReduce(max) on the device word itself (sph_slab_flag_buffer), grouped ncclSend / ncclRecv on the
+ *         device buffers (sph_slab_buffers) on a second stream; one rank per GPU (RCCL does not share a device)
+ *   host  the same protocol with POSIX shared memory between the ranks: the word through sph_slab_flag_get / _set, the
+ *         buffers through sph_slab_copy_out / _copy_in, a process-shared barrier between writing and reading.  Ranks may
+ *         share a device: rehearsals and tests of THIS file's step loop, re-balancing and statistics on a one-GPU box.
+ * The two differ only in the functions under "transport" below; the step loop is one.
+ *
+ *   slab_sph_fluid --ranks N [--transport rccl|host] [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--origin X0 Y0]
+ *                  [--velocity U V] [--steps K] [--warmup W] [--tilt] [--check] [--deterministic] [--skin F]
+ *                  [--rebalance-every K] [--capacity N] [--console] [--frame FILE] [--dump-state FILE]
+ * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
+ * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
+ * what may sit under a profiler; the launcher must not: see profiles/README.md).  The ncclUniqueId travels through a file
+ * (--id-file, made by the launcher), the shared memory through its name (--shm).  --scene dam: N lattice blocks of
  * 4000 x 500 (2 000 000 particles per GPU, box 1200 N x 60 m: the cfg2 -> cfg3 weak-scaling family); cfg3 / cfg4: the
  * fixed 8M / 32M scenes; --tilt: gravity from the scripted tilt trace (sph_gravity, the MPU6050 stand-in), sampled every
  * step with its 0.1 s hold.  Every rank generates only the lattice columns it holds.
@@ -28,11 +39,14 @@
 #include <rccl/rccl.h>
 
 #include <errno.h>
+#include <fcntl.h>
 #include <math.h>
+#include <pthread.h>
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <time.h>
@@ -44,6 +58,7 @@
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, hipGetErrorString(e_)); return 1; } } while (0)
 #define NCCLCHK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, ncclGetErrorString(r_)); return 1; } } while (0)
 #define SPHCHK(ctx, call) do { int rc_ = (call); if (rc_ != SPH_OK) { fprintf(stderr, "[rank %d] %s: %d (%s)\n", g_rank, #call, rc_, (ctx) ? sph_last_error(ctx) : sph_error_string(rc_)); return 1; } } while (0)
+#define CHK(call) do { if ((call) != 0) return 1; } while (0)
 
 static int g_rank = 0;
 
@@ -54,47 +69,329 @@ static double now_s(void) {
 }
 
 typedef struct {
-    float box_w, box_h, x0, y0;
+    float box_w, box_h, x0, y0, u0, v0;
     long nx, ny;
     const char *label;
 } scene_t;
 
-/* ---- launcher: N ranks, before anything touches a GPU ---- */
-static int launch(int nranks, int argc, char **argv) {
-    char idfile[256];
-    snprintf(idfile, sizeof idfile, "/tmp/slab_sph_fluid.%d.%ld.id", (int)getpid(), (long)time(NULL));
-    unlink(idfile);
+/* ------------------------------------------------------------------------------------------------------------------
+ * transport: what the step loop needs from the ranks' interconnect
+ * ---------------------------------------------------------------------------------------------------------------- */
+enum { TR_RCCL = 0, TR_HOST = 1 };
+
+typedef struct shm_hdr {
+    pthread_barrier_t bar;
+    int nranks;
+    size_t halo_bytes, coll_bytes, coll_off, mail_off, total;
+} shm_hdr;
+
+typedef struct comm {
+    int kind, rank, nranks;
+    /* rccl */
+    ncclComm_t nccl;
+    void *d_coll;                 /* device staging of the small collectives */
+    /* host */
+    shm_hdr *shm;
+    char shm_name[160];
+    unsigned long seq;            /* collectives so far (parity: which of the two slots / mailboxes) */
+    unsigned long xseq;           /* all-to-all exchanges so far (names of their segments) */
+    size_t coll_bytes, halo_bytes;
+} comm;
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static size_t shm_layout(shm_hdr *h, int nranks, size_t halo_bytes, size_t coll_bytes) {
+    h->nranks = nranks;
+    h->halo_bytes = align_up(halo_bytes, 64);
+    h->coll_bytes = align_up(coll_bytes, 64);
+    h->coll_off = align_up(sizeof(shm_hdr), 4096);
+    h->mail_off = align_up(h->coll_off + 2 * (size_t)nranks * h->coll_bytes, 4096);
+    h->total = h->mail_off + 2 * (size_t)nranks * 2 * h->halo_bytes;
+    return h->total;
+}
+static unsigned char *shm_coll(comm *cm, unsigned long parity, int r) {
+    return (unsigned char *)cm->shm + cm->shm->coll_off + ((size_t)(parity & 1ul) * (size_t)cm->nranks + (size_t)r) * cm->shm->coll_bytes;
+}
+static unsigned char *shm_mail(comm *cm, unsigned long parity, int r, int side) {
+    return (unsigned char *)cm->shm + cm->shm->mail_off + (((size_t)(parity & 1ul) * (size_t)cm->nranks + (size_t)r) * 2 + (size_t)side) * cm->shm->halo_bytes;
+}
+
+/* create (launcher, or the one in-process rank) or open (a rank) the shared segment */
+static int shm_create(const char *name, int nranks, size_t halo_bytes, size_t coll_bytes) {
+    shm_hdr tmp;
+    const size_t total = shm_layout(&tmp, nranks, halo_bytes, coll_bytes);
+    shm_unlink(name);
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) { perror("shm_open"); return 1; }
+    if (ftruncate(fd, (off_t)total) != 0) { perror("ftruncate"); close(fd); shm_unlink(name); return 1; }
+    shm_hdr *h = (shm_hdr *)mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (h == MAP_FAILED) { perror("mmap"); shm_unlink(name); return 1; }
+    shm_layout(h, nranks, halo_bytes, coll_bytes);
+    pthread_barrierattr_t at;
+    pthread_barrierattr_init(&at);
+    pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
+    const int rc = pthread_barrier_init(&h->bar, &at, (unsigned)nranks);
+    pthread_barrierattr_destroy(&at);
+    munmap(h, total);
+    if (rc != 0) { fprintf(stderr, "pthread_barrier_init: %s\n", strerror(rc)); shm_unlink(name); return 1; }
+    return 0;
+}
+static int shm_attach(comm *cm, const char *name) {
+    const int fd = shm_open(name, O_RDWR, 0600);
+    if (fd < 0) { fprintf(stderr, "[rank %d] shm_open(%s): %s\n", cm->rank, name, strerror(errno)); return 1; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size < (off_t)sizeof(shm_hdr)) { close(fd); return 1; }
+    cm->shm = (shm_hdr *)mmap(NULL, (size_t)sb.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (cm->shm == MAP_FAILED) { cm->shm = NULL; return 1; }
+    if (cm->shm->nranks != cm->nranks || cm->shm->total != (size_t)sb.st_size) { fprintf(stderr, "[rank %d] shared segment %s does not match this run\n", cm->rank, name); return 1; }
+    snprintf(cm->shm_name, sizeof cm->shm_name, "%s", name);
+    return 0;
+}
+
+static int comm_barrier(comm *cm) {
+    if (cm->nranks == 1) return 0;
+    if (cm->kind == TR_HOST) {
+        const int rc = pthread_barrier_wait(&cm->shm->bar);
+        return rc != 0 && rc != PTHREAD_BARRIER_SERIAL_THREAD;
+    }
+    int one = 1;      /* (a 4-byte all-reduce: RCCL has no barrier call) */
+    HIPCHK(hipMemcpy(cm->d_coll, &one, sizeof one, hipMemcpyHostToDevice));
+    NCCLCHK(ncclAllReduce(cm->d_coll, cm->d_coll, 1, ncclInt32, ncclSum, cm->nccl, NULL));
+    HIPCHK(hipStreamSynchronize(NULL));
+    return 0;
+}
+
+/* element-wise reduction of a small host array over all ranks, in place: op 0 = sum of int64, 1 = max of float */
+static int comm_allreduce(comm *cm, void *buf, size_t count, int op) {
+    const size_t esz = op == 0 ? sizeof(long long) : sizeof(float), bytes = count * esz;
+    if (cm->nranks == 1) return 0;
+    if (bytes > cm->coll_bytes) { fprintf(stderr, "[rank %d] collective of %zu bytes exceeds the staging size %zu\n", cm->rank, bytes, cm->coll_bytes); return 1; }
+    if (cm->kind == TR_RCCL) {
+        HIPCHK(hipMemcpy(cm->d_coll, buf, bytes, hipMemcpyHostToDevice));
+        NCCLCHK(ncclAllReduce(cm->d_coll, cm->d_coll, count, op == 0 ? ncclInt64 : ncclFloat32, op == 0 ? ncclSum : ncclMax, cm->nccl, NULL));
+        HIPCHK(hipStreamSynchronize(NULL));
+        HIPCHK(hipMemcpy(buf, cm->d_coll, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    const unsigned long par = cm->seq++;
+    memcpy(shm_coll(cm, par, cm->rank), buf, bytes);
+    CHK(comm_barrier(cm));      /* (the slot of this parity is written again two collectives later: a barrier lies in between) */
+    for (int r = 0; r < cm->nranks; r++) {
+        if (r == cm->rank) continue;
+        if (op == 0) {
+            const long long *o = (const long long *)shm_coll(cm, par, r);
+            for (size_t k = 0; k < count; k++) ((long long *)buf)[k] += o[k];
+        } else {
+            const float *o = (const float *)shm_coll(cm, par, r);
+            for (size_t k = 0; k < count; k++) if (o[k] > ((float *)buf)[k]) ((float *)buf)[k] = o[k];
+        }
+    }
+    return 0;
+}
+
+/* the rebuild word of this step, MAX-reduced over the ranks, on the context's stream */
+static int comm_reduce_word(comm *cm, sph_ctx *ctx, void *dev_word, hipStream_t st) {
+    if (cm->nranks == 1) return 0;
+    if (cm->kind == TR_RCCL) {
+        NCCLCHK(ncclAllReduce(dev_word, dev_word, 1, ncclUint32, ncclMax, cm->nccl, st));    /* 4 bytes, on the device word */
+        return 0;
+    }
+    uint32_t w = 0;
+    SPHCHK(ctx, sph_slab_flag_get(ctx, &w));
+    float f = (float)w;
+    CHK(comm_allreduce(cm, &f, 1, 1));
+    SPHCHK(ctx, sph_slab_flag_set(ctx, f > 0.0f ? 1u : 0u));
+    return 0;
+}
+
+typedef struct xchg {      /* what the exchange of a step needs besides the communicator */
+    void *send_l, *send_r, *recv_l, *recv_r;
+    size_t halo_bytes;
+    int has_left, has_right;
+    hipStream_t st, xst;
+    hipEvent_t packed, arrived;
+} xchg;
+
+/* the halo exchange of this step with sph_slab_step_overlap beside it; on return the receive buffers are (rccl: will be,
+ * in stream order) filled and sph_slab_step_end may follow */
+static int comm_exchange(comm *cm, sph_ctx *ctx, const xchg *x) {
+    if (!(x->has_left || x->has_right)) return 0;
+    if (cm->kind == TR_RCCL) {
+        /* the exchange on its own stream, behind the pack; the interior density pass runs beside it */
+        HIPCHK(hipEventRecord(x->packed, x->st));
+        HIPCHK(hipStreamWaitEvent(x->xst, x->packed, 0));
+        NCCLCHK(ncclGroupStart());
+        if (x->has_left) {
+            NCCLCHK(ncclSend(x->send_l, x->halo_bytes, ncclChar, cm->rank - 1, cm->nccl, x->xst));
+            NCCLCHK(ncclRecv(x->recv_l, x->halo_bytes, ncclChar, cm->rank - 1, cm->nccl, x->xst));
+        }
+        if (x->has_right) {
+            NCCLCHK(ncclSend(x->send_r, x->halo_bytes, ncclChar, cm->rank + 1, cm->nccl, x->xst));
+            NCCLCHK(ncclRecv(x->recv_r, x->halo_bytes, ncclChar, cm->rank + 1, cm->nccl, x->xst));
+        }
+        NCCLCHK(ncclGroupEnd());
+        HIPCHK(hipEventRecord(x->arrived, x->xst));
+        SPHCHK(ctx, sph_slab_step_overlap(ctx));
+        HIPCHK(hipStreamWaitEvent(x->st, x->arrived, 0));
+        return 0;
+    }
+    const unsigned long par = cm->seq++;
+    if (x->has_left) SPHCHK(ctx, sph_slab_copy_out(ctx, 0, shm_mail(cm, par, cm->rank, 0)));
+    if (x->has_right) SPHCHK(ctx, sph_slab_copy_out(ctx, 1, shm_mail(cm, par, cm->rank, 1)));
+    SPHCHK(ctx, sph_slab_step_overlap(ctx));
+    CHK(comm_barrier(cm));
+    if (x->has_left) SPHCHK(ctx, sph_slab_copy_in(ctx, 0, shm_mail(cm, par, cm->rank - 1, 1)));       /* what the left neighbour sent right */
+    if (x->has_right) SPHCHK(ctx, sph_slab_copy_in(ctx, 1, shm_mail(cm, par, cm->rank + 1, 0)));
+    return 0;
+}
+
+/* every rank sends cnt[q] records of `recw` floats to every rank q (re-balancing): out[q] -> what arrives, concatenated
+ * in rank order, in *in (malloc'd) / *n_in */
+static int comm_alltoallv(comm *cm, float *const *out, const long long *cnt, int recw, float **in, long long *n_in) {
+    const int n = cm->nranks;
+    long long *mat = (long long *)calloc((size_t)n * (size_t)n, sizeof(long long));      /* mat[s * n + d] = records s -> d */
+    if (!mat) return 1;
+    for (int q = 0; q < n; q++) mat[(size_t)cm->rank * n + q] = cnt[q];
+    if (comm_allreduce(cm, mat, (size_t)n * (size_t)n, 0)) { free(mat); return 1; }
+    long long total = 0;
+    for (int s = 0; s < n; s++) total += mat[(size_t)s * n + cm->rank];
+    float *dst = (float *)malloc(sizeof(float) * (size_t)recw * (size_t)(total ? total : 1));
+    if (!dst) { free(mat); return 1; }
+    const size_t rb = sizeof(float) * (size_t)recw;
+    int rc = 0;
+    if (cm->kind == TR_RCCL && n > 1) {
+        long long sent = 0;
+        for (int q = 0; q < n; q++) sent += q == cm->rank ? 0 : cnt[q];
+        const long long recv = total - mat[(size_t)cm->rank * n + cm->rank];
+        float *d_s = NULL, *d_r = NULL;
+        if (hipMalloc((void **)&d_s, rb * (size_t)(sent ? sent : 1)) != hipSuccess || hipMalloc((void **)&d_r, rb * (size_t)(recv ? recv : 1)) != hipSuccess) rc = 1;
+        long long so = 0;
+        for (int q = 0; q < n && !rc; q++) {
+            if (q == cm->rank || !cnt[q]) continue;
+            if (hipMemcpy((char *)d_s + rb * (size_t)so, out[q], rb * (size_t)cnt[q], hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+            so += cnt[q];
+        }
+        if (!rc) {
+            ncclGroupStart();
+            long long s_off = 0, r_off = 0;
+            for (int q = 0; q < n; q++) {
+                if (q == cm->rank) continue;
+                const long long a = cnt[q], b = mat[(size_t)q * n + cm->rank];
+                if (a) ncclSend((char *)d_s + rb * (size_t)s_off, rb * (size_t)a, ncclChar, q, cm->nccl, NULL);
+                if (b) ncclRecv((char *)d_r + rb * (size_t)r_off, rb * (size_t)b, ncclChar, q, cm->nccl, NULL);
+                s_off += a;
+                r_off += b;
+            }
+            if (ncclGroupEnd() != ncclSuccess || hipStreamSynchronize(NULL) != hipSuccess) rc = 1;
+        }
+        long long o = 0, r_off = 0;
+        for (int s = 0; s < n && !rc; s++) {      /* rank order: what came from the others out of d_r, the own part from memory */
+            const long long b = mat[(size_t)s * n + cm->rank];
+            if (s == cm->rank) memcpy((char *)dst + rb * (size_t)o, out[s], rb * (size_t)b);
+            else if (b) {
+                if (hipMemcpy((char *)dst + rb * (size_t)o, (char *)d_r + rb * (size_t)r_off, rb * (size_t)b, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+                r_off += b;
+            }
+            o += b;
+        }
+        if (d_s) (void)hipFree(d_s);
+        if (d_r) (void)hipFree(d_r);
+    } else if (n > 1) {      /* host: one shared segment per (source, destination) pair that carries anything */
+        const unsigned long seq = cm->xseq++;
+        char name[256];
+        for (int q = 0; q < n && !rc; q++) {
+            if (q == cm->rank || !cnt[q]) continue;
+            snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->shm_name, seq, cm->rank, q);
+            shm_unlink(name);
+            const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+            const size_t bytes = rb * (size_t)cnt[q];
+            void *m = MAP_FAILED;
+            if (fd >= 0 && ftruncate(fd, (off_t)bytes) == 0) m = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (fd >= 0) close(fd);
+            if (m == MAP_FAILED) { rc = 1; break; }
+            memcpy(m, out[q], bytes);
+            munmap(m, bytes);
+        }
+        if (comm_barrier(cm)) rc = 1;
+        long long o = 0;
+        for (int s = 0; s < n && !rc; s++) {
+            const long long b = mat[(size_t)s * n + cm->rank];
+            if (s == cm->rank) memcpy((char *)dst + rb * (size_t)o, out[s], rb * (size_t)b);
+            else if (b) {
+                snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->shm_name, seq, s, cm->rank);
+                const int fd = shm_open(name, O_RDONLY, 0600);
+                const size_t bytes = rb * (size_t)b;
+                void *m = fd >= 0 ? mmap(NULL, bytes, PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;
+                if (fd >= 0) close(fd);
+                if (m == MAP_FAILED) { rc = 1; break; }
+                memcpy((char *)dst + rb * (size_t)o, m, bytes);
+                munmap(m, bytes);
+            }
+            o += b;
+        }
+        if (comm_barrier(cm)) rc = 1;
+        for (int q = 0; q < n; q++) {
+            if (q == cm->rank || !cnt[q]) continue;
+            snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->shm_name, seq, cm->rank, q);
+            shm_unlink(name);
+        }
+    } else {
+        memcpy(dst, out[0], rb * (size_t)total);
+    }
+    free(mat);
+    if (rc) { free(dst); return 1; }
+    *in = dst;
+    *n_in = total;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * launcher: N ranks, before anything touches a GPU
+ * ---------------------------------------------------------------------------------------------------------------- */
+static int launch(int nranks, int argc, char **argv, const char *idfile, const char *shm_name) {
     pid_t *pids = (pid_t *)calloc((size_t)nranks, sizeof(pid_t));
+    if (!pids) return 1;
+    int worst = 0, started = 0;
     for (int r = 0; r < nranks; r++) {
         pid_t pid = fork();
-        if (pid < 0) { perror("fork"); return 1; }
+        if (pid < 0) { perror("fork"); worst = 1; break; }
         if (pid == 0) {
-            char **av = (char **)calloc((size_t)argc + 6, sizeof(char *));
+            char **av = (char **)calloc((size_t)argc + 8, sizeof(char *));
             char rbuf[16];
             snprintf(rbuf, sizeof rbuf, "%d", r);
             int k = 0;
             for (int i = 0; i < argc; i++) av[k++] = argv[i];
-            av[k++] = "--rank"; av[k++] = rbuf; av[k++] = "--id-file"; av[k++] = idfile; av[k] = NULL;
+            av[k++] = "--rank"; av[k++] = rbuf; av[k++] = "--id-file"; av[k++] = (char *)idfile;
+            if (shm_name) { av[k++] = "--shm"; av[k++] = (char *)shm_name; }
+            av[k] = NULL;
             execv("/proc/self/exe", av);
             perror("execv");
             _exit(127);
         }
         pids[r] = pid;
+        started++;
     }
-    int worst = 0, left = nranks;
+    int left = started, killed = 0, first_fail = 0;
+    if (worst) {                                   /* fork failed: the ranks already started would wait for the others */
+        for (int r = 0; r < nranks; r++) if (pids[r] > 0) kill(pids[r], SIGTERM);
+        killed = 1;
+    }
     while (left > 0) {
         int status = 0;
         pid_t pid = wait(&status);
         if (pid < 0) break;
         left--;
+        for (int r = 0; r < nranks; r++) if (pids[r] == pid) pids[r] = 0;      /* reaped: never signal this pid again */
         const int rc = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
-        if (rc != 0) {                         /* one rank failed: the others would wait for it forever */
-            if (rc > worst) worst = rc;
-            for (int r = 0; r < nranks; r++)
-                if (pids[r] != pid) kill(pids[r], SIGTERM);
+        if (rc != 0 && !killed) {                  /* one rank failed: the others would wait for it forever */
+            first_fail = rc;
+            for (int r = 0; r < nranks; r++) if (pids[r] > 0) kill(pids[r], SIGTERM);
+            killed = 1;
         }
     }
-    unlink(idfile);
+    if (first_fail) worst = first_fail;
     free(pids);
     return worst;
 }
@@ -131,19 +428,160 @@ static float max_abs_diff(const sph_particle *a, const sph_particle *b, const un
     return m;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * one rank
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct rank_state {
+    sph_params prm;
+    comm cm;
+    int device, transport, deterministic, capacity;
+    sph_particle *walls;
+    long nw;
+    hipStream_t st, xst;
+    hipEvent_t packed, arrived;
+    sph_ctx *ctx;
+    int c0, c1;                  /* owned columns */
+    void *flag;
+    xchg x;
+} rank_state;
+
+/* a slab context for columns [c0, c1) from the particles given, wired to the rank's streams and transport */
+static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc, const unsigned *ids, long n_loc, float gx, float gy) {
+    sph_slab_desc desc = {c0, c1, rs->cm.rank > 0, rs->cm.rank < rs->cm.nranks - 1, 0, rs->capacity};
+    rs->ctx = NULL;
+    SPHCHK(rs->ctx, sph_create_slab(&rs->ctx, &rs->prm, &desc, loc, ids, (int)n_loc, rs->walls, (int)rs->nw, gx, gy, rs->device));
+    SPHCHK(rs->ctx, sph_set_stream(rs->ctx, rs->st));
+    /* one rank per GPU (rccl): nothing else computes on this device, so what follows the halo exchange may run as one
+     * launch with grid barriers (include/sph.h, sph_set_rebuild_launches); ranks that may share a device must not */
+    if (rs->transport == TR_RCCL) SPHCHK(rs->ctx, sph_set_rebuild_launches(rs->ctx, 1));
+    SPHCHK(rs->ctx, sph_slab_flag_buffer(rs->ctx, &rs->flag));
+    SPHCHK(rs->ctx, sph_slab_buffers(rs->ctx, &rs->x.send_l, &rs->x.send_r, &rs->x.recv_l, &rs->x.recv_r, &rs->x.halo_bytes));
+    if (rs->transport == TR_HOST && rs->cm.nranks > 1 && rs->x.halo_bytes > rs->cm.halo_bytes) {
+        fprintf(stderr, "[rank %d] halo buffers of %zu bytes exceed the shared mailboxes (%zu)\n", rs->cm.rank, rs->x.halo_bytes, rs->cm.halo_bytes);
+        return 1;
+    }
+    rs->x.has_left = desc.has_left;
+    rs->x.has_right = desc.has_right;
+    rs->x.st = rs->st;
+    rs->x.xst = rs->xst;
+    rs->x.packed = rs->packed;
+    rs->x.arrived = rs->arrived;
+    rs->c0 = c0;
+    rs->c1 = c1;
+    return 0;
+}
+
+/* one time step (:612-641) of this rank's slab */
+static int step_once(rank_state *rs, float gx, float gy) {
+    SPHCHK(rs->ctx, sph_slab_step_begin(rs->ctx, gx, gy));
+    CHK(comm_reduce_word(&rs->cm, rs->ctx, rs->flag, rs->st));
+    SPHCHK(rs->ctx, sph_slab_step_pack(rs->ctx));
+    CHK(comm_exchange(&rs->cm, rs->ctx, &rs->x));
+    SPHCHK(rs->ctx, sph_slab_step_end(rs->ctx));
+    return 0;
+}
+
+/* Dynamic re-balancing: new column ranges at the quantiles of the CURRENT per-column particle histogram
+ * (summed over the ranks), every particle shipped to the slab that now holds its column (owned + 2 ghost columns), the
+ * slab context re-created from what arrived — it evaluates rho, p, a from (x, v) like the reference's init sequence
+ * (:604-607): the run is continued, not bit-continued.  Collective.  *moved = 0 when the largest slab would shrink by
+ * less than min_gain (nothing is touched then). */
+static int rebalance(rank_state *rs, float gx, float gy, double min_gain, int *moved) {
+    comm *cm = &rs->cm;
+    const int n = cm->nranks, cols = sph_slab_grid_columns(&rs->prm);
+    *moved = 0;
+    int n_local = 0, n_owned = 0, n_out = 0;
+    SPHCHK(rs->ctx, sph_slab_counts(rs->ctx, &n_local, &n_owned));
+    sph_particle *own = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)(n_owned + 1));
+    unsigned *ids = (unsigned *)malloc(sizeof(unsigned) * (size_t)(n_owned + 1));
+    long long *hist = (long long *)calloc((size_t)cols + (size_t)n, sizeof(long long));      /* per column, then per rank */
+    int *cuts = (int *)calloc((size_t)n + 1, sizeof(int)), *pcol = (int *)malloc(sizeof(int) * (size_t)(n_owned + 1));
+    if (!own || !ids || !hist || !cuts || !pcol) return 1;
+    SPHCHK(rs->ctx, sph_slab_read(rs->ctx, own, ids, NULL, NULL, n_owned, &n_out));
+    for (int k = 0; k < n_out; k++) {
+        int c = sph_slab_column_of(&rs->prm, own[k].x);
+        c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+        pcol[k] = c;
+        hist[c]++;
+    }
+    hist[cols + cm->rank] = n_out;
+    CHK(comm_allreduce(cm, hist, (size_t)cols + (size_t)n, 0));
+    if (sph_slab_partition_counts(hist, cols, n, cuts) != SPH_OK) { fprintf(stderr, "[rank %d] re-balancing: the fluid is too narrow for %d slabs\n", cm->rank, n); return 1; }
+    long long old_max = 0, new_max = 0, run = 0;
+    for (int r = 0; r < n; r++) if (hist[cols + r] > old_max) old_max = hist[cols + r];
+    for (int r = 0, c = 0; r < n; r++) {
+        for (run = 0; c < cuts[r + 1]; c++) run += hist[c];
+        if (run > new_max) new_max = run;
+    }
+    if ((double)(old_max - new_max) < min_gain * (double)(old_max > 1 ? old_max : 1)) {
+        free(own); free(ids); free(hist); free(cuts); free(pcol);
+        return 0;
+    }
+    /* records {x, y, u, v, m, rho, p, id}: to every slab whose columns [c0 - 2, c1 + 2) hold the particle */
+    enum { RECW = 8 };
+    long long *cnt = (long long *)calloc((size_t)n, sizeof(long long));
+    float **out = (float **)calloc((size_t)n, sizeof(float *));
+    if (!cnt || !out) return 1;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass) for (int q = 0; q < n; q++) { out[q] = (float *)malloc(sizeof(float) * RECW * (size_t)(cnt[q] + 1)); if (!out[q]) return 1; cnt[q] = 0; }
+        for (int k = 0; k < n_out; k++)
+            for (int q = 0; q < n; q++)
+                if (pcol[k] >= cuts[q] - 2 && pcol[k] < cuts[q + 1] + 2) {
+                    if (pass) {
+                        float *r = out[q] + (size_t)RECW * (size_t)cnt[q];
+                        memcpy(r, &own[k], sizeof(sph_particle));
+                        memcpy(r + 7, &ids[k], sizeof(unsigned));
+                    }
+                    cnt[q]++;
+                }
+    }
+    float *in = NULL;
+    long long n_in = 0;
+    CHK(comm_alltoallv(cm, out, cnt, RECW, &in, &n_in));
+    sph_particle *loc = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)(n_in + 1));
+    unsigned *lid = (unsigned *)malloc(sizeof(unsigned) * (size_t)(n_in + 1));
+    if (!loc || !lid) return 1;
+    for (long long k = 0; k < n_in; k++) {
+        memcpy(&loc[k], in + (size_t)RECW * (size_t)k, sizeof(sph_particle));
+        memcpy(&lid[k], in + (size_t)RECW * (size_t)k + 7, sizeof(unsigned));
+    }
+    HIPCHK(hipStreamSynchronize(rs->st));
+    HIPCHK(hipStreamSynchronize(rs->xst));
+    sph_destroy(rs->ctx);
+    CHK(make_context(rs, cuts[cm->rank], cuts[cm->rank + 1], loc, lid, (long)n_in, gx, gy));
+    *moved = 1;
+    for (int q = 0; q < n; q++) free(out[q]);
+    free(out); free(cnt); free(in); free(loc); free(lid);
+    free(own); free(ids); free(hist); free(cuts); free(pcol);
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    int nranks = 1, rank = -1, steps = 200, warmup = 50, tilt = 0, check = 0, deterministic = 0;
+    int nranks = 1, rank = -1, steps = 200, warmup = 50, tilt = 0, check = 0, deterministic = 0, transport = TR_RCCL;
+    int rebalance_every = 0, capacity = 0, console = 0;
     float skin = -1;
-    const char *scene_name = "dam", *idfile = NULL;
-    scene_t sc = {0, 0, 0.3f, 0.3f, 0, 0, NULL};
+    const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL;
+    scene_t sc = {0, 0, 0.3f, 0.3f, 0, 0, 0, 0, NULL};
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--ranks") && i + 1 < argc) nranks = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--rank") && i + 1 < argc) rank = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--id-file") && i + 1 < argc) idfile = argv[++i];
+        else if (!strcmp(argv[i], "--shm") && i + 1 < argc) shm_name = argv[++i];
+        else if (!strcmp(argv[i], "--transport") && i + 1 < argc) {
+            const char *t = argv[++i];
+            if (!strcmp(t, "rccl")) transport = TR_RCCL;
+            else if (!strcmp(t, "host")) transport = TR_HOST;
+            else { fprintf(stderr, "unknown transport %s (rccl | host)\n", t); return 2; }
+        }
         else if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene_name = argv[++i];
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--rebalance-every") && i + 1 < argc) rebalance_every = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--capacity") && i + 1 < argc) capacity = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--frame") && i + 1 < argc) frame_file = argv[++i];
+        else if (!strcmp(argv[i], "--dump-state") && i + 1 < argc) state_file = argv[++i];
         else if (!strcmp(argv[i], "--tilt")) tilt = 1;
+        else if (!strcmp(argv[i], "--console")) console = 1;
         else if (!strcmp(argv[i], "--deterministic")) deterministic = 1;
         else if (!strcmp(argv[i], "--skin") && i + 1 < argc) skin = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--check")) check = 1;
@@ -151,13 +589,13 @@ int main(int argc, char **argv) {
             sc.nx = atol(argv[++i]); sc.ny = atol(argv[++i]); sc.box_w = (float)atof(argv[++i]); sc.box_h = (float)atof(argv[++i]);
             sc.label = "custom block";
         }
+        else if (!strcmp(argv[i], "--origin") && i + 2 < argc) { sc.x0 = (float)atof(argv[++i]); sc.y0 = (float)atof(argv[++i]); }
+        else if (!strcmp(argv[i], "--velocity") && i + 2 < argc) { sc.u0 = (float)atof(argv[++i]); sc.v0 = (float)atof(argv[++i]); }
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
-    if (nranks < 1 || steps < 0 || warmup < 0) return 2;
-    if (rank < 0) return launch(nranks, argc, argv);
-    g_rank = rank;
+    if (nranks < 1 || steps < 0 || warmup < 0 || rebalance_every < 0) return 2;
 
-    /* ---- scene: parameters and this rank's columns ---- */
+    /* ---- scene and parameters (the launcher needs them too: the size of the shared mailboxes) ---- */
     if (!sc.nx) {
         if (!strcmp(scene_name, "dam")) { sc.nx = 4000L * nranks; sc.ny = 500; sc.box_w = 1200.0f * (float)nranks; sc.box_h = 60.0f; sc.label = "dam break, 2 000 000 fluid particles per slab"; }
         else if (!strcmp(scene_name, "cfg3")) { sc.nx = 16000; sc.ny = 500; sc.box_w = 2400.0f; sc.box_h = 60.0f; sc.label = "cfg3: 8M dam break"; }
@@ -170,6 +608,41 @@ int main(int argc, char **argv) {
     if (skin >= 0) prm.skin = skin;
     prm.x_max = sc.box_w;
     prm.y_max = sc.box_h;
+    const int cols = sph_slab_grid_columns(&prm);
+    const size_t halo_bytes = sph_slab_halo_bytes(&prm, 0);
+    size_t coll_bytes = sizeof(long long) * ((size_t)cols + (size_t)nranks * (size_t)nranks + 64);      /* histogram + counts ... */
+    if (coll_bytes < 16384) coll_bytes = 16384;                                                          /* ... or the 1024 bytes of a frame as int64 */
+
+    char idbuf[256], shmbuf[160];
+    if (rank < 0) {
+        snprintf(idbuf, sizeof idbuf, "/tmp/slab_sph_fluid.%d.%ld.id", (int)getpid(), (long)time(NULL));
+        snprintf(shmbuf, sizeof shmbuf, "/slab_sph_fluid.%d.%ld", (int)getpid(), (long)time(NULL));
+        unlink(idbuf);
+        if (transport == TR_HOST && nranks > 1 && shm_create(shmbuf, nranks, halo_bytes, coll_bytes)) return 1;
+        if (nranks > 1) {
+            const int rc = launch(nranks, argc, argv, idbuf, transport == TR_HOST ? shmbuf : NULL);
+            unlink(idbuf);
+            if (transport == TR_HOST) shm_unlink(shmbuf);
+            return rc;
+        }
+        rank = 0;                      /* one rank: in this process (no fork, no exec) */
+        idfile = idbuf;
+    }
+    g_rank = rank;
+
+    rank_state rs;
+    memset(&rs, 0, sizeof rs);
+    rs.prm = prm;
+    rs.transport = transport;
+    rs.deterministic = deterministic;
+    rs.capacity = capacity;
+    rs.cm.kind = transport;
+    rs.cm.rank = rank;
+    rs.cm.nranks = nranks;
+    rs.cm.coll_bytes = coll_bytes;
+    rs.cm.halo_bytes = (halo_bytes + 63) / 64 * 64;
+
+    /* ---- this rank's columns and particles ---- */
     int *cuts = (int *)calloc((size_t)nranks + 1, sizeof(int));
     SPHCHK(NULL, sph_slab_partition_block(&prm, sc.x0, sc.nx, sc.ny, nranks, cuts));
     const int c0 = cuts[rank], c1 = cuts[rank + 1];
@@ -178,119 +651,166 @@ int main(int argc, char **argv) {
     const long n_loc = (ie - ib) * sc.ny, n_total = sc.nx * sc.ny;
     sph_particle *loc = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)(n_loc ? n_loc : 1));
     unsigned *ids = (unsigned *)malloc(sizeof(unsigned) * (size_t)(n_loc ? n_loc : 1));
-    const long nw = sph_scene_walls(&prm, 0, NULL, 0);
-    sph_particle *walls = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)nw);
-    if (!loc || !ids || !walls) { fprintf(stderr, "[rank %d] out of host memory\n", rank); return 1; }
+    rs.nw = sph_scene_walls(&prm, 0, NULL, 0);
+    rs.walls = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)rs.nw);
+    if (!loc || !ids || !rs.walls) { fprintf(stderr, "[rank %d] out of host memory\n", rank); return 1; }
     if (sph_scene_block_range(&prm, sc.x0, sc.y0, sc.nx, sc.ny, ib, ie, loc, n_loc) != n_loc) return 1;
-    for (long k = 0; k < n_loc; k++) ids[k] = (unsigned)(ib * sc.ny + k);
-    sph_scene_walls(&prm, 0, walls, nw);
+    for (long k = 0; k < n_loc; k++) { ids[k] = (unsigned)(ib * sc.ny + k); loc[k].u = sc.u0; loc[k].v = sc.v0; }
+    sph_scene_walls(&prm, 0, rs.walls, rs.nw);
 
     sph_gravity grav;
     sph_gravity_init(&grav, tilt ? SPH_GRAVITY_TILT : SPH_GRAVITY_CONSTANT, prm.g);
     float gx, gy, t = 0;
     sph_gravity_sample(&grav, 0.0f, &gx, &gy);
 
-    /* ---- device, streams, slab context ---- */
+    /* ---- device, streams, communicator, slab context ---- */
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         fprintf(stderr, "[rank %d] no HIP device available (this program has no CPU path)\n", rank);
         return 1;
     }
-    if (nranks > ndev) {
-        fprintf(stderr, "[rank %d] %d ranks need %d GPUs (found %d): RCCL does not share a device between ranks\n", rank, nranks, nranks, ndev);
+    if (transport == TR_RCCL && nranks > ndev) {
+        fprintf(stderr, "[rank %d] %d ranks need %d GPUs (found %d): RCCL does not share a device between ranks "
+                        "(--transport host rehearses the same step loop on fewer)\n", rank, nranks, nranks, ndev);
         return 1;
     }
-    const int device = rank;
-    HIPCHK(hipSetDevice(device));
-    hipStream_t st, xst;                       /* compute stream (adopted by the context) and exchange stream */
-    hipEvent_t packed, arrived;
-    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&xst, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&packed, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&arrived, hipEventDisableTiming));
-    sph_slab_desc desc = {c0, c1, rank > 0, rank < nranks - 1, 0, 0};
-    sph_ctx *ctx = NULL;
+    rs.device = transport == TR_RCCL ? rank : rank % ndev;
+    HIPCHK(hipSetDevice(rs.device));
+    HIPCHK(hipStreamCreateWithFlags(&rs.st, hipStreamNonBlocking));      /* compute stream (adopted by the context) ... */
+    HIPCHK(hipStreamCreateWithFlags(&rs.xst, hipStreamNonBlocking));     /* ... and exchange stream */
+    HIPCHK(hipEventCreateWithFlags(&rs.packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&rs.arrived, hipEventDisableTiming));
+    if (transport == TR_RCCL) {
+        ncclUniqueId id;
+        if (nranks == 1) NCCLCHK(ncclGetUniqueId(&id));
+        else if (!idfile || exchange_id(idfile, rank, &id)) { fprintf(stderr, "[rank %d] could not exchange the ncclUniqueId\n", rank); return 1; }
+        NCCLCHK(ncclCommInitRank(&rs.cm.nccl, nranks, id, rank));
+        if (rank == 0 && nranks > 1 && idfile) unlink(idfile);           /* every rank has joined: the file is spent */
+        HIPCHK(hipMalloc(&rs.cm.d_coll, coll_bytes));
+    } else if (nranks > 1) {
+        if (!shm_name) { fprintf(stderr, "[rank %d] --transport host needs --shm (the launcher passes it)\n", rank); return 1; }
+        CHK(shm_attach(&rs.cm, shm_name));
+    }
     const double t_create = now_s();
-    SPHCHK(ctx, sph_create_slab(&ctx, &prm, &desc, loc, ids, (int)n_loc, walls, (int)nw, gx, gy, device));
-    SPHCHK(ctx, sph_set_stream(ctx, st));
-    void *flag = NULL, *send_l = NULL, *send_r = NULL, *recv_l = NULL, *recv_r = NULL;
-    size_t halo_bytes = 0;
-    SPHCHK(ctx, sph_slab_flag_buffer(ctx, &flag));
-    SPHCHK(ctx, sph_slab_buffers(ctx, &send_l, &send_r, &recv_l, &recv_r, &halo_bytes));
+    CHK(make_context(&rs, c0, c1, loc, ids, n_loc, gx, gy));
     int n_local = 0, n_owned = 0;
-    SPHCHK(ctx, sph_slab_counts(ctx, &n_local, &n_owned));
-    fprintf(stderr, "[rank %d] columns [%d,%d) of %d, lattice columns [%ld,%ld), local/owned %d/%d, created in %.2f s, halo buffers %zu B\n",
-            rank, c0, c1, sph_slab_grid_columns(&prm), ib, ie, n_local, n_owned, now_s() - t_create, halo_bytes);
-
-    /* ---- communicator ---- */
-    ncclUniqueId id;
-    ncclComm_t comm;
-    if (!idfile || exchange_id(idfile, rank, &id)) { fprintf(stderr, "[rank %d] could not exchange the ncclUniqueId\n", rank); return 1; }
-    NCCLCHK(ncclCommInitRank(&comm, nranks, id, rank));
-    unsigned long long *d_sum = NULL;          /* owned-particle count for the conservation check */
-    HIPCHK(hipMalloc((void **)&d_sum, sizeof *d_sum));
+    SPHCHK(rs.ctx, sph_slab_counts(rs.ctx, &n_local, &n_owned));
+    fprintf(stderr, "[rank %d] columns [%d,%d) of %d, lattice columns [%ld,%ld), local/owned %d/%d, created in %.2f s, halo buffers %zu B, device %d, %s transport\n",
+            rank, c0, c1, cols, ib, ie, n_local, n_owned, now_s() - t_create, rs.x.halo_bytes, rs.device, transport == TR_RCCL ? "rccl" : "host");
+    if (console && rank == 0) {
+        printf("dt = %f    (expected ticks/s) %d\n", prm.dt, (int)(1 / prm.dt));      /* :543 */
+        printf("n_fluid = %ld\n", n_total);                                            /* :544 */
+        printf("n_boundary = %ld\n", rs.nw);                                           /* :545 */
+    }
 
     /* ---- step loop ---- */
-    const int has_nb = desc.has_left || desc.has_right;
-    double t0 = 0;
+    double t0 = 0, last_reported = now_s();
+    float last_t = 0, worst_rho_err = 0, worst_speed = 0;
+    int rebalanced = 0;
     for (int s = 0; s < warmup + steps; s++) {
         if (s == warmup) {
-            HIPCHK(hipStreamSynchronize(st));
-            HIPCHK(hipStreamSynchronize(xst));
-            NCCLCHK(ncclAllReduce(d_sum, d_sum, 1, ncclUint64, ncclSum, comm, st));      /* barrier across ranks */
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipStreamSynchronize(rs.st));
+            HIPCHK(hipStreamSynchronize(rs.xst));
+            CHK(comm_barrier(&rs.cm));
             t0 = now_s();
         }
-        SPHCHK(ctx, sph_slab_step_begin(ctx, gx, gy));
-        if (nranks > 1) NCCLCHK(ncclAllReduce(flag, flag, 1, ncclUint32, ncclMax, comm, st));    /* 4 bytes, on the device word */
-        SPHCHK(ctx, sph_slab_step_pack(ctx));
-        if (has_nb) {
-            /* the exchange on its own stream, behind the pack; the interior density pass runs beside it */
-            HIPCHK(hipEventRecord(packed, st));
-            HIPCHK(hipStreamWaitEvent(xst, packed, 0));
-            NCCLCHK(ncclGroupStart());
-            if (desc.has_left) {
-                NCCLCHK(ncclSend(send_l, halo_bytes, ncclChar, rank - 1, comm, xst));
-                NCCLCHK(ncclRecv(recv_l, halo_bytes, ncclChar, rank - 1, comm, xst));
-            }
-            if (desc.has_right) {
-                NCCLCHK(ncclSend(send_r, halo_bytes, ncclChar, rank + 1, comm, xst));
-                NCCLCHK(ncclRecv(recv_r, halo_bytes, ncclChar, rank + 1, comm, xst));
-            }
-            NCCLCHK(ncclGroupEnd());
-            HIPCHK(hipEventRecord(arrived, xst));
-            SPHCHK(ctx, sph_slab_step_overlap(ctx));
-            HIPCHK(hipStreamWaitEvent(st, arrived, 0));
-        }
-        SPHCHK(ctx, sph_slab_step_end(ctx));
+        CHK(step_once(&rs, gx, gy));
         t += prm.dt;                                                             /* :678 */
+        if (console && t - last_t > 0.1f) {                                      /* the reference's console line, :679-691 */
+            float mx[2] = {0, 0};
+            SPHCHK(rs.ctx, sph_stats(rs.ctx, &mx[0], &mx[1]));                   /* :657-671 over the owned particles ... */
+            CHK(comm_allreduce(&rs.cm, mx, 2, 1));                               /* ... and the maximum over the ranks */
+            const double now = now_s();
+            const float rho_err = (mx[0] - prm.rho0) / prm.rho0 * 100;
+            if (rho_err > worst_rho_err) worst_rho_err = rho_err;
+            if (mx[1] > worst_speed) worst_speed = mx[1];
+            if (rank == 0) {
+                printf("sim time: %.2f, ", t);
+                printf("ticks/s: %d, ", (int)(((t - last_t) / prm.dt) / (now - last_reported)));
+                printf("max rho error: %.3f%% (worst) %.3f%%, ", rho_err, worst_rho_err);
+                printf("max speed: %.1f m/s (worst) %.1f m/s, ", mx[1], worst_speed);
+                printf("\n");
+                fflush(stdout);
+            }
+            last_t = t;
+            last_reported = now;
+        }
         sph_gravity_sample(&grav, t, &gx, &gy);                                  /* 10 Hz hold, :455-461 */
+        if (rebalance_every && (s + 1) % rebalance_every == 0 && s + 1 < warmup + steps) {
+            int rc = sph_sync(rs.ctx);                                           /* capacity / out-of-domain / NaN so far */
+            if (rc) { fprintf(stderr, "[rank %d] sph_sync before re-balancing: %d (%s)\n", rank, rc, sph_last_error(rs.ctx)); return 1; }
+            int moved = 0;
+            CHK(rebalance(&rs, gx, gy, 0.05, &moved));
+            if (moved) {
+                rebalanced++;
+                SPHCHK(rs.ctx, sph_slab_counts(rs.ctx, &n_local, &n_owned));
+                fprintf(stderr, "[rank %d] re-balanced after step %d: columns [%d,%d), local/owned %d/%d\n", rank, s + 1, rs.c0, rs.c1, n_local, n_owned);
+            }
+        }
     }
-    HIPCHK(hipStreamSynchronize(st));
-    NCCLCHK(ncclAllReduce(d_sum, d_sum, 1, ncclUint64, ncclSum, comm, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(rs.st));
+    HIPCHK(hipStreamSynchronize(rs.xst));
+    CHK(comm_barrier(&rs.cm));
     const double elapsed = now_s() - t0;
-    int rc = sph_sync(ctx);                                                      /* capacity / out-of-domain / NaN */
-    if (rc) { fprintf(stderr, "[rank %d] sph_sync: %d (%s)\n", rank, rc, sph_last_error(ctx)); return 1; }
+    int rc = sph_sync(rs.ctx);                                                   /* capacity / out-of-domain / NaN */
+    if (rc) { fprintf(stderr, "[rank %d] sph_sync: %d (%s)\n", rank, rc, sph_last_error(rs.ctx)); return 1; }
 
-    /* ---- conservation: every particle owned exactly once ---- */
-    SPHCHK(ctx, sph_slab_counts(ctx, &n_local, &n_owned));
-    unsigned long long owned = (unsigned long long)n_owned, owned_total = 0;
-    HIPCHK(hipMemcpy(d_sum, &owned, sizeof owned, hipMemcpyHostToDevice));
-    NCCLCHK(ncclAllReduce(d_sum, d_sum, 1, ncclUint64, ncclSum, comm, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipMemcpy(&owned_total, d_sum, sizeof owned_total, hipMemcpyDeviceToHost));
+    /* ---- conservation: every particle owned exactly once; statistics; the frame ---- */
+    SPHCHK(rs.ctx, sph_slab_counts(rs.ctx, &n_local, &n_owned));
+    long long owned_total = n_owned, max_owned_ll = n_owned;
+    CHK(comm_allreduce(&rs.cm, &owned_total, 1, 0));
+    float fm[3] = {0, 0, (float)n_owned};
+    SPHCHK(rs.ctx, sph_stats(rs.ctx, &fm[0], &fm[1]));
+    CHK(comm_allreduce(&rs.cm, fm, 3, 1));
+    max_owned_ll = (long long)fm[2];
+    unsigned char page[1024];
+    long long page_ll[1024];
+    if (frame_file) {                                                            /* draw_metaballs :380-411 on every slab; the pages OR-ed */
+        SPHCHK(rs.ctx, sph_render_metaballs(rs.ctx, page));
+        for (int k = 0; k < 1024; k++) page_ll[k] = page[k];                     /* (every pixel belongs to one slab: the sum IS the OR) */
+        CHK(comm_allreduce(&rs.cm, page_ll, 1024, 0));
+        if (rank == 0) {
+            for (int k = 0; k < 1024; k++) page[k] = (unsigned char)page_ll[k];
+            FILE *fh = fopen(frame_file, "wb");
+            if (!fh || fwrite(page, 1, 1024, fh) != 1024) { fprintf(stderr, "cannot write %s\n", frame_file); return 1; }
+            fclose(fh);
+        }
+    }
     long long rebuilds = 0, direct = 0;
-    sph_rebuild_stats(ctx, &rebuilds, &direct);
+    sph_rebuild_stats(rs.ctx, &rebuilds, &direct);
     if (rank == 0) {
         const double tps = steps > 0 ? (double)steps / elapsed : 0.0;
-        printf("{\"host\": \"slab_sph_fluid (C, RCCL)\", \"workload\": \"%s%s\", \"n_gpus\": %d, \"n_fluid\": %ld, \"n_boundary\": %ld, "
+        printf("{\"host\": \"slab_sph_fluid (C, %s)\", \"workload\": \"%s%s\", \"n_gpus\": %d, \"n_fluid\": %ld, \"n_boundary\": %ld, "
                "\"steps\": %d, \"warmup\": %d, \"ticks_per_s\": %.2f, \"mparticle_steps_per_s\": %.2f, \"ms_per_step\": %.5f, "
-               "\"neighbour_rebuilds\": %lld, \"particles_conserved\": %s}\n",
-               sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, nw, steps, warmup, tps, tps * (double)n_total / 1e6,
-               steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, owned_total == (unsigned long long)n_total ? "true" : "false");
+               "\"neighbour_rebuilds\": %lld, \"rebalanced\": %d, \"max_owned\": %lld, \"max_rho\": %.3f, \"max_speed\": %.3f, \"particles_conserved\": %s}\n",
+               transport == TR_RCCL ? "RCCL" : "host-staged shared memory", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
+               steps, warmup, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
+               owned_total == (long long)n_total ? "true" : "false");
+        fflush(stdout);
     }
-    if (owned_total != (unsigned long long)n_total) { fprintf(stderr, "[rank %d] particles lost: %llu of %ld\n", rank, owned_total, n_total); return 1; }
+    if (owned_total != (long long)n_total) { fprintf(stderr, "[rank %d] particles lost: %lld of %ld\n", rank, owned_total, n_total); return 1; }
+
+    /* ---- --dump-state: every rank's owned particles into one file, by global id (records of sph_particle) ---- */
+    if (state_file) {
+        sph_particle *got = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)(n_owned + 1));
+        unsigned *gid = (unsigned *)malloc(sizeof(unsigned) * (size_t)(n_owned + 1));
+        int n_out = 0;
+        if (!got || !gid) return 1;
+        SPHCHK(rs.ctx, sph_slab_read(rs.ctx, got, gid, NULL, NULL, n_owned, &n_out));
+        if (rank == 0) {                               /* rank 0 makes the file, then everybody writes its records in place */
+            FILE *fh = fopen(state_file, "wb");
+            if (!fh || ftruncate(fileno(fh), (off_t)(sizeof(sph_particle) * (size_t)n_total)) != 0) { fprintf(stderr, "cannot write %s\n", state_file); return 1; }
+            fclose(fh);
+        }
+        CHK(comm_barrier(&rs.cm));
+        const int fd = open(state_file, O_WRONLY);
+        if (fd < 0) { fprintf(stderr, "[rank %d] cannot open %s\n", rank, state_file); return 1; }
+        for (int k = 0; k < n_out; k++)
+            if (pwrite(fd, &got[k], sizeof(sph_particle), (off_t)(sizeof(sph_particle) * (size_t)gid[k])) != (ssize_t)sizeof(sph_particle)) return 1;
+        close(fd);
+        CHK(comm_barrier(&rs.cm));
+        free(got); free(gid);
+    }
 
     /* ---- --check (one rank): the same run through sph_step on a single context ---- */
     if (check) {
@@ -298,14 +818,14 @@ int main(int argc, char **argv) {
         sph_particle *got = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)n_total);
         unsigned *gid = (unsigned *)malloc(sizeof(unsigned) * (size_t)n_total);
         int n_out = 0;
-        SPHCHK(ctx, sph_slab_read(ctx, got, gid, NULL, NULL, (int)n_total, &n_out));
+        SPHCHK(rs.ctx, sph_slab_read(rs.ctx, got, gid, NULL, NULL, (int)n_total, &n_out));
         if (n_out != n_total) { fprintf(stderr, "sph_slab_read returned %d of %ld particles\n", n_out, n_total); return 1; }
         sph_ctx *one = NULL;
         sph_gravity g2;
         sph_gravity_init(&g2, tilt ? SPH_GRAVITY_TILT : SPH_GRAVITY_CONSTANT, prm.g);
         float hx, hy, t2 = 0;
         sph_gravity_sample(&g2, 0.0f, &hx, &hy);
-        SPHCHK(one, sph_create(&one, &prm, loc, (int)n_total, walls, (int)nw, hx, hy, device));
+        SPHCHK(one, sph_create(&one, &prm, loc, (int)n_total, rs.walls, (int)rs.nw, hx, hy, rs.device));
         for (int s = 0; s < warmup + steps; s++) {
             SPHCHK(one, sph_step(one, hx, hy, 1));
             t2 += prm.dt;
@@ -322,9 +842,8 @@ int main(int argc, char **argv) {
         free(got); free(gid); free(ref);
         if (!(dx <= tol)) return 1;
     }
-    ncclCommDestroy(comm);
-    sph_destroy(ctx);
-    (void)hipFree(d_sum);
-    free(loc); free(ids); free(walls); free(cuts);
+    if (transport == TR_RCCL) { ncclCommDestroy(rs.cm.nccl); (void)hipFree(rs.cm.d_coll); }
+    sph_destroy(rs.ctx);
+    free(loc); free(ids); free(rs.walls); free(cuts);
     return 0;
 }

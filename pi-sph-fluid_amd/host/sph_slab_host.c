@@ -23,18 +23,11 @@ int sph_slab_column_of(const sph_params *p, float x) {
     return (int)((x - p->x_min) * inv);
 }
 
-int sph_slab_partition_block(const sph_params *p, float x0, long nx, long ny, int world, int *cuts) {
-    if (!p || !cuts || nx <= 0 || ny <= 0 || world < 1) return SPH_E_ARG;
-    const int cols = sph_slab_grid_columns(p);
+int sph_slab_partition_counts(const long long *hist, int cols, int world, int *cuts) {
+    if (!hist || !cuts || cols < 1 || world < 1) return SPH_E_ARG;
     double *cum = (double *)calloc((size_t)cols, sizeof(double));
     if (!cum) return SPH_E_NOMEM;
-    for (long i = 0; i < nx; i++) {                       /* per-column particle counts follow from the lattice */
-        int c = sph_slab_column_of(p, x0 + (float)i * p->r);
-        if (c < 0) c = 0;
-        if (c > cols - 1) c = cols - 1;
-        cum[c] += (double)ny;
-    }
-    for (int c = 1; c < cols; c++) cum[c] += cum[c - 1];
+    for (int c = 0; c < cols; c++) cum[c] = (double)hist[c] + (c ? cum[c - 1] : 0.0);
     const double total = cum[cols - 1];
     cuts[0] = 0;                                          /* the slabs tile the whole box */
     for (int r = 1; r < world; r++) {
@@ -55,6 +48,22 @@ int sph_slab_partition_block(const sph_params *p, float x0, long nx, long ny, in
     for (int r = 0; r < world; r++)
         if (cuts[r + 1] - cuts[r] < 4 || cuts[r] < 0) return SPH_E_ARG;      /* scene too narrow for that many slabs */
     return SPH_OK;
+}
+
+int sph_slab_partition_block(const sph_params *p, float x0, long nx, long ny, int world, int *cuts) {
+    if (!p || !cuts || nx <= 0 || ny <= 0 || world < 1) return SPH_E_ARG;
+    const int cols = sph_slab_grid_columns(p);
+    long long *hist = (long long *)calloc((size_t)cols, sizeof(long long));
+    if (!hist) return SPH_E_NOMEM;
+    for (long i = 0; i < nx; i++) {                       /* per-column particle counts follow from the lattice */
+        int c = sph_slab_column_of(p, x0 + (float)i * p->r);
+        if (c < 0) c = 0;
+        if (c > cols - 1) c = cols - 1;
+        hist[c] += (long long)ny;
+    }
+    const int rc = sph_slab_partition_counts(hist, cols, world, cuts);
+    free(hist);
+    return rc;
 }
 
 int sph_slab_block_columns(const sph_params *p, float x0, long nx, int col_begin, int col_end, long *i_begin, long *i_end) {

@@ -248,6 +248,29 @@ class GpuSlab:
         self._chk(self.L.sph_slab_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def stats(self):
+        """max rho and max speed over the particles this slab owns (the host takes the maximum over the ranks)."""
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.L.sph_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def render(self):
+        """this slab's part of the 128 x 64 metaball frame (1024 bytes, SSD1306 page format): the pixels whose centres lie in
+        its owned columns; the bitwise OR over all slabs is the frame."""
+        buf = np.zeros(1024, np.uint8)
+        self._chk(self.L.sph_render_metaballs(self.h, buf.ctypes.data_as(C.c_void_p)))
+        return buf
+
+    def set_rebuild_launches(self, one_launch):
+        """True: what follows the halo exchange runs as ONE kernel with grid barriers.  Only when nothing else computes on
+        the device while this slab steps (one rank per GPU, or slabs stepped strictly one after the other)."""
+        self._chk(self.L.sph_set_rebuild_launches(self.h, 1 if one_launch else 0))
+
+    def diagnostics(self):
+        a = (C.c_longlong * 7)()
+        self._chk(self.L.sph_direct_tile_reasons(self.h, a))
+        return tuple(int(x) for x in a)
+
     def rebuilds(self):
         """rebuilds of the neighbour structure since creation (the same number on every slab)."""
         a, b = C.c_longlong(), C.c_longlong()
@@ -372,9 +395,13 @@ class SlabRunner:
     """nsteps of: kick/drift -> reduce the rebuild word -> halo pack -> exchange (beside it: density of the interior
     tiles) -> (ingest + sort + lists | ghost update) + density of the rest + force (pi_sph_fluid.c:612-641)."""
 
-    def __init__(self, slabs, transport, overlap=None, factory=None, prm=None, rank0=0, world=None):
+    def __init__(self, slabs, transport, overlap=None, factory=None, prm=None, rank0=0, world=None, serialize=False):
         """factory(c0, c1, has_left, has_right, particles, ids, gx, gy) -> a new slab: needed only by rebalance(), with
-        prm (the scene's parameters), rank0 (global index of this process's first slab) and world (slabs in total)."""
+        prm (the scene's parameters), rank0 (global index of this process's first slab) and world (slabs in total).
+        serialize: the slabs of this process finish their steps strictly one after the other (a synchronisation after
+        every sph_slab_step_end): what slabs that share a device owe each other when they run what follows the halo
+        exchange as one launch with grid barriers (GpuSlab.set_rebuild_launches)."""
+        self.serialize = serialize
         self.slabs = slabs if isinstance(slabs, (list, tuple)) else [slabs]
         self.transport = transport
         self.factory, self.prm, self.rank0 = factory, prm, rank0
@@ -400,6 +427,8 @@ class SlabRunner:
             self.transport.exchange_finish(handle)
             for s in self.slabs:
                 s.step_end()
+                if self.serialize:
+                    s.sync()
 
     RECW = 8      # words per particle in a re-balancing message: x, y, u, v, m, rho, p, id (bits)
 

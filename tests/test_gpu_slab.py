@@ -264,3 +264,66 @@ def test_deterministic_slabs_equal_single_bitwise(sph, orc):
         assert ctx.rebuild_stats()[0] >= 150
     for s in slabs:
         s.close()
+
+
+def test_one_launch_slabs_equal_per_phase_bitwise(sph, orc):
+    """What follows a slab's halo exchange as ONE launch with grid barriers (k_rebuild_slab: ghost update, or ingest of the
+    received records -> scan -> scatter -> canonical order -> lists) against one kernel per phase, WITH neighbours: three slabs
+    of the developed block share the device, finish their steps strictly one after the other (serialize: a slab's barrier
+    kernel needs the device to itself) and have asked for one launch (sph_set_rebuild_launches — this is what every rank of
+    the C host does on its own GPU).  Deterministic order, skin 0: a rebuild with migration in every step, the same bits."""
+    g = load_golden("block.npz")
+    prm = sph.default_params(tuple(g["box"]), 0.0, deterministic=True)
+    f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))
+    b = boundary_particles(orc, g["boundary_xy"])
+    world, outs = 3, []
+    for one_launch in (False, True):
+        parts = sph.slab.partition_columns(prm, f, world, slack=8)
+        slabs = [sph.slab.GpuSlab(sph, prm, f, b, c0, c1, r > 0, r < world - 1, GX, GY) for r, (c0, c1) in enumerate(parts)]
+        if one_launch:
+            for s in slabs:
+                s.set_rebuild_launches(True)
+        runner = sph.slab.SlabRunner(slabs, sph.slab.LocalTransport(slabs), serialize=one_launch)
+        ids0 = [s.read()[1].copy() for s in slabs]
+        runner.step(120, GX, GY)
+        for s in slabs:
+            s.sync()
+            assert (s.L.sph_get_rebuild_launches(s.h) == 1) == one_launch
+        out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+        assert np.all(seen == 1)
+        migrated = sum(len(set(s.read()[1].tolist()) - set(i0.tolist())) for s, i0 in zip(slabs, ids0))
+        assert migrated > 0 and slabs[0].rebuilds() >= 120
+        outs.append((out, du, dv))
+        for s in slabs:
+            s.close()
+    for k in ("x", "y", "u", "v", "rho", "p"):
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_slab_metaballs_and_stats(sph, orc):
+    """sph_render_metaballs / sph_stats on slab contexts: every slab renders the pixels of its owned columns, the OR of the
+    pages is the single context's frame (<= 2 threshold pixels: neighbour sums in another order); the maxima of the slabs'
+    statistics are the single context's."""
+    prm, f, b = sph.scene("cfg0")
+    world = 2
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.step(1000, GX, GY)
+        ctx.sync()
+        cur = ctx.read_particles()
+        page = ctx.render_metaballs()
+        mr, ms = ctx.stats()
+    cur["rho"] = prm.rho0
+    cur["p"] = 0
+    parts = sph.slab.partition_columns(prm, cur, world)
+    slabs = [sph.slab.GpuSlab(sph, prm, cur, b, c0, c1, r > 0, r < world - 1, GX, GY) for r, (c0, c1) in enumerate(parts)]
+    pages = [s.render() for s in slabs]
+    assert all(p.any() for p in pages) or sum(p.any() for p in pages) >= 1
+    both = np.bitwise_or.reduce(pages)
+    assert not np.any(pages[0] & pages[1])                        # every pixel belongs to one slab
+    assert int(np.unpackbits(both ^ page).sum()) <= 2
+    st = [s.stats() for s in slabs]
+    assert abs(max(x[0] for x in st) - mr) <= 2e-3 * mr           # (rho re-evaluated from the positions at creation)
+    assert abs(max(x[1] for x in st) - ms) <= 1e-6 * max(ms, 1.0)
+    for s in slabs:
+        s.close()

@@ -106,3 +106,125 @@ def test_c_host_deterministic_equals_sph_step_bitwise(sph):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     chk = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("check:")]
     assert len(chk) == 1 and "max|dx| = 0.000e+00" in chk[0] and "max|drho| = 0.000e+00" in chk[0], chk
+
+
+def test_c_partition_counts_equals_python(sph):
+    """the re-balancing cuts of the C host (sph_slab_partition_counts) equal the Python host's (_cuts_from_histogram)"""
+    L = sph.host_lib()
+    rng = np.random.default_rng(3)
+    for cols, world in ((64, 2), (300, 3), (5352, 8), (40, 4)):
+        hist = rng.integers(0, 500, cols).astype(np.int64)
+        hist[: cols // 5] = 0                                     # a dry stretch
+        cuts = (C.c_int * (world + 1))()
+        assert L.sph_slab_partition_counts(hist.ctypes.data_as(C.POINTER(C.c_longlong)), cols, world, cuts) == 0
+        assert [(cuts[r], cuts[r + 1]) for r in range(world)] == sph.slab._cuts_from_histogram(hist, world, 0, cols)
+    hist = np.ones(10, np.int64)
+    cuts = (C.c_int * 5)()
+    assert L.sph_slab_partition_counts(hist.ctypes.data_as(C.POINTER(C.c_longlong)), 10, 4, cuts) == sph.SPH_E_ARG
+
+
+def _run_host(args, timeout=600):
+    r = subprocess.run([HOST] + [str(a) for a in args], capture_output=True, timeout=timeout)
+    out = r.stdout.decode().splitlines()
+    rec = [json.loads(ln) for ln in out if ln.startswith("{")]
+    return r, out, (rec[0] if rec else None)
+
+
+def _flying_block(sph, u=5.0, deterministic=True, skin=0.0):
+    prm, f, b = sph.scene_block((0.0, 90.0, 0.0, 20.0), 0.3, 0.3, 600, 150)
+    prm.deterministic = 1 if deterministic else 0
+    if skin is not None:
+        prm.skin = skin
+    f["u"] = u
+    return prm, f, b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_c_host_ranks_over_shared_memory_equal_sph_step_bitwise(sph, tmp_path, ranks):
+    """THE STEP LOOP OF THE C HOST WITH NEIGHBOURS, on one GPU: 2 and 4 ranks (processes) exchange the halo buffers and
+    reduce the rebuild word through POSIX shared memory (--transport host: sph_slab_copy_out / _copy_in, sph_slab_flag_get /
+    _set) in the order the RCCL transport uses.  A block flying along x at 5 m/s (particles migrate between the slabs),
+    deterministic order, skin 0 (both sides rebuild every step): after 300 steps the ranks' particles equal sph_step's bit by bit."""
+    state = tmp_path / "state.bin"
+    r, out, rec = _run_host(["--ranks", ranks, "--transport", "host", "--block", 600, 150, 90, 20, "--velocity", 5, 0, "--steps", 250,
+                             "--warmup", 50, "--deterministic", "--skin", 0, "--dump-state", state])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["n_gpus"] == ranks and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True and rec["neighbour_rebuilds"] >= 300
+    assert "shared memory" in rec["host"]
+    got = np.fromfile(state, sph.PARTICLE)
+    prm, f, b = _flying_block(sph)
+    with sph.Context(prm, f, b, 0.0, -9.81) as ctx:
+        ctx.step(300, 0.0, -9.81)
+        ctx.sync()
+        ref = ctx.read_particles()
+    assert len(got) == len(ref)
+    for k in ("x", "y", "u", "v", "rho", "p"):
+        assert np.array_equal(got[k], ref[k]), k
+    # the slabs did exchange owners: the block moved 0.37 m = 1.6 cell columns
+    assert np.abs(ref["x"] - f["x"]).max() > 0.3
+
+
+@pytest.mark.gpu
+def test_c_host_shared_memory_default_skin_console_and_frame(sph, tmp_path):
+    """default skin (lists reused; the ranks must agree on the steps that rebuild): every particle owned once, the run close to
+    sph_step's; the reference's console line (:679-691) with the maxima reduced over the ranks; the metaball frame OR-ed
+    from the ranks' pages equals the single context's up to threshold pixels (a 8 x 4 m box: pixels of 6 cm)."""
+    state, frame = tmp_path / "state.bin", tmp_path / "frame.bin"
+    r, out, rec = _run_host(["--ranks", 3, "--transport", "host", "--block", 80, 40, 8, 4, "--velocity", 1, 0, "--steps", 500,
+                             "--warmup", 0, "--console", "--frame", frame, "--dump-state", state])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 500
+    assert out[0].startswith("dt = ") and out[1] == "n_fluid = 3200" and out[2].startswith("n_boundary = ")
+    lines = [ln for ln in out if ln.startswith("sim time: ")]
+    assert len(lines) == 1                                        # 500 steps = 0.122 s of simulated time: one line
+    import re
+    m = re.match(r"sim time: (\d+\.\d\d), ticks/s: (\d+), max rho error: (-?\d+\.\d{3})% \(worst\) (-?\d+\.\d{3})%, "
+                 r"max speed: (\d+\.\d) m/s \(worst\) (\d+\.\d) m/s, $", lines[0])
+    assert m, lines[0]
+    got = np.fromfile(state, sph.PARTICLE)
+    prm, f, b = sph.scene_block((0.0, 8.0, 0.0, 4.0), 0.3, 0.3, 80, 40)
+    f["u"] = 1.0
+    with sph.Context(prm, f, b, 0.0, -9.81) as ctx:
+        ctx.step(500, 0.0, -9.81)
+        ctx.sync()
+        ref = ctx.read_particles()
+        page = ctx.render_metaballs()
+        mr, ms = ctx.stats()
+    # (a lattice block collapsing under gravity: the two runs differ by summation order and by the steps in which they
+    # rebuild, and the flow amplifies that; the bit-exact comparison is the test above)
+    assert max(np.abs(got["x"] - ref["x"]).max(), np.abs(got["y"] - ref["y"]).max()) <= 5e-3
+    assert np.max(np.abs(got["rho"] - ref["rho"]) / ref["rho"]) <= 2e-2
+    assert abs(rec["max_rho"] - mr) <= 1e-2 * mr and abs(rec["max_speed"] - ms) <= 2e-2 * ms
+    assert 0.5 < float(m.group(5)) < 4.0                          # the block moves at 1 m/s and falls
+    fr = np.fromfile(frame, np.uint8)
+    assert len(fr) == 1024 and fr.any() and page.any()
+    assert int(np.unpackbits(fr ^ page).sum()) <= 4
+
+
+@pytest.mark.gpu
+def test_c_host_rebalancing_keeps_a_migrating_flow_inside_capacity(sph, tmp_path):
+    """Re-balancing in the C host: a block flying along x at 30 m/s leaves the first slab and piles into the
+    last one.  With the static partition the last rank runs out of particle capacity (SPH_E_CAPACITY: reported, and the
+    launcher ends the other ranks); with --rebalance-every 150 the run goes through, every particle stays owned exactly once,
+    the slabs stay balanced and the result is the single context's (a re-created slab re-evaluates a from (x, v): the run is
+    continued, not bit-continued; the block moves as a whole, so the comparison is tight)."""
+    base = ["--ranks", 3, "--transport", "host", "--block", 160, 40, 60, 6, "--origin", 2.0, 1.5, "--velocity", 30, 0,
+            "--capacity", 3200, "--warmup", 0, "--steps", 900]
+    r, out, rec = _run_host(base)
+    assert r.returncode != 0 and b"capacity" in r.stderr, r.stderr.decode()[-2000:]
+    state = tmp_path / "state.bin"
+    r, out, rec = _run_host(base + ["--rebalance-every", 150, "--dump-state", state])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["particles_conserved"] is True and rec["rebalanced"] >= 3
+    # (balanced at step 750; in the 150 steps since, 1.1 m = 5 cell columns of 120 particles have flown on)
+    assert rec["max_owned"] <= 6400 // 3 + 700
+    got = np.fromfile(state, sph.PARTICLE)
+    prm, f, b = sph.scene_block((0.0, 60.0, 0.0, 6.0), 2.0, 1.5, 160, 40)
+    f["u"] = 30.0
+    with sph.Context(prm, f, b, 0.0, -9.81) as ctx:
+        ctx.step(900, 0.0, -9.81)
+        ctx.sync()
+        ref = ctx.read_particles()
+    assert max(np.abs(got["x"] - ref["x"]).max(), np.abs(got["y"] - ref["y"]).max()) <= 5e-4
+    assert np.abs(ref["x"] - f["x"]).min() > 6.0                  # the block did fly: 30 m/s x 0.22 s
