@@ -58,8 +58,9 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
-def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False):
-    """K timed steps of one scene on device 0; returns a result dict.  tilt: gravity from the scripted tilt trace
+def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False, windows=1):
+    """`windows` timed windows of `steps` steps each of one scene on device 0, after `warmup` steps; returns a result dict
+    (rates: the median window; windows = 1: exactly `steps` timed steps).  tilt: gravity from the scripted tilt trace
     (sph_gravity: 15 deg, 8 s period, re-sampled every 0.1 s of simulated time like the reference's 10 Hz poll,
     pi_sph_fluid.c:455-461), one sph_step call per step as the reference re-reads g every step (:632)."""
     prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
@@ -86,14 +87,22 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
     del f
     advance(warmup)
     ctx.sync()
-    r0, _ = ctx.rebuild_stats()
-    t0 = time.perf_counter()
-    advance(steps)
-    ctx.sync()
-    dt = time.perf_counter() - t0
-    r1, _ = ctx.rebuild_stats()
+    rates, rebuilt = [], []
+    for _ in range(windows):
+        r0, _d = ctx.rebuild_stats()
+        t0 = time.perf_counter()
+        advance(steps)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        r1, _d = ctx.rebuild_stats()
+        rates.append(steps / dt)
+        rebuilt.append((r1 - r0) / max(steps, 1))
+    mid = int(np.argsort(rates)[len(rates) // 2])          # the median window (its own rebuild rate goes with it)
     kt = ctx.profile_steps(profile_steps, *(grav.sample(sim[0] * dt_sim) if grav else (0.0, -9.81)))      # HIP events on the kernels' own stream
     ctx.sync()
+    # sph_profile_steps launches one kernel per phase of the rebuild chain with an event around each (sph_step itself
+    # launches the chain as one kernel and eight steps as one graph): its sum is not the step time of the timed loop
+    kt["profiled_step_separate_launches"] = kt.pop("step")
     # the two heavy kernels are idempotent: time back-to-back launches on the live state (no per-launch
     # event overhead; this is the figure that must agree with rocprofv3's average kernel duration)
     kt["density_eos"] = ctx.time_kernel("density_eos", 50)
@@ -102,10 +111,12 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
     rows, cols = ctx.grid_dims()
     rebuilds, direct_tiles = ctx.rebuild_stats()
     res = {"workload": name, "n_fluid": n, "n_boundary": len(b), "grid_cells": rows * cols,
-           "steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
-           "mparticle_steps_per_s": steps / dt * n / 1e6, "kernel_ms": kt,
+           "steps_per_s": rates[mid], "ms_per_step": 1e3 / rates[mid],
+           "mparticle_steps_per_s": rates[mid] * n / 1e6, "kernel_ms": kt,
            "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s, "skin_frac": float(prm.skin),
-           "rebuilds": rebuilds, "direct_tiles": direct_tiles, "timed_rebuilds_per_step": (r1 - r0) / max(steps, 1),
+           "rebuilds": rebuilds, "direct_tiles": direct_tiles, "timed_rebuilds_per_step": rebuilt[mid],
+           "window_steps_per_s": [round(x, 2) for x in rates], "window_rebuilds_per_step": [round(x, 4) for x in rebuilt],
+           "windows": windows, "window_steps": steps, "warmup": warmup,
            "device_mb": ctx.device_bytes() / 1e6}
     ctx.close()
     return res
@@ -119,9 +130,10 @@ ALGO_PER_REBUILD = 4.0 + 5.2 + 1.2 + 44.0
 FORCE_FUSED_NET = 40.0 + 40.0 - 24.0        # the fusion keeps x, y, u, v, ax, ay in registers: P1's 24 B of reads never happen
 
 
-def roofline(sph, res):
+def roofline(sph, res, traffic_key=None):
     """HBM roofline of the dominant kernel: algorithmic bytes per launch / its mean launch duration (HIP events on the
-    kernels' own stream, back-to-back launches on the live state)."""
+    kernels' own stream, back-to-back launches on the live state).  traffic: PMC bytes per launch of that kernel in the
+    same regime of the same workload (profiles/traffic.json: collected offline with rocprofv3, profiles/README.md)."""
     kt = res["kernel_ms"]
     cand = {k: kt[k] for k in ("kick_drift", "density_eos", "force_kick")}
     dom = max(cand, key=cand.get)
@@ -135,7 +147,7 @@ def roofline(sph, res):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):          # PMC passes are collected offline with rocprofv3 (see profiles/README.md)
         try:
-            traffic = json.load(open(tpath)).get(res["workload"], {}).get(dom)
+            traffic = json.load(open(tpath)).get(traffic_key or res["workload"], {}).get(dom)
         except Exception:
             traffic = None
     out = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -222,12 +234,31 @@ def cpu_baseline(sph, name, nsteps=20, windows=3):
         legs.append({"label": label, "threads": threads, "timesteps_per_s": round(rate, 4),
                      "value": round(rate * d["n"] / 1e6, 3), "windows": [round(x, 4) for x in d["rates"]]})
         log("cpu_baseline:", legs[-1])
+    if not legs:          # (neither leg ran: the GPU result is still worth a line)
+        return None
     best = max(legs, key=lambda l: l["value"])
-    return {"value": best["value"], "unit": "Mparticle-steps/s", "timesteps_per_s": best["timesteps_per_s"],
+    res = {"value": best["value"], "unit": "Mparticle-steps/s", "timesteps_per_s": best["timesteps_per_s"],
             "cores": best["threads"], "kind": "port", "legs": legs,
             "sample": "median of %d windows of %d steps (after 2 warm-up) of the full %s scene, %d fluid particles; best of two "
                       "legs (%s); host: %s, %d physical cores / %d logical CPUs available to this process"
                       % (windows, nsteps, name, n_fluid, best["label"], model, len(cores), logical)}
+    try:          # the N > 1 runs of the same box quote it (they do not measure it again)
+        with open(CPU_CACHE, "w") as fh:
+            json.dump(dict(res, cached_from="the N = 1 run of bench.py on this host"), fh)
+    except OSError:
+        pass
+    return res
+
+
+CPU_CACHE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sph_bench_cpu_baseline_%d.json" % os.getuid())
+
+
+def cached_cpu_baseline():
+    try:
+        with open(CPU_CACHE) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
 
 
 def launch_ranks(args):
@@ -273,19 +304,28 @@ def launch_ranks(args):
 def run_c_host(sph, args):
     """N > 1 (default): the C multi-GPU host (pi-sph-fluid_amd/host/slab_sph_fluid.c: one process per GPU, halo
     exchange and rebuild-word reduction over RCCL, no torch in the loop).  Started here as N ranks, or — under torchrun
-    — as the one rank this process stands for (the ncclUniqueId then travels through a file named after the job)."""
+    — as the one rank this process stands for (the ncclUniqueId then travels through a file named after the job).
+    --transport host: the same step loop with POSIX shared memory between the ranks (they may share a device: a
+    rehearsal of the N-rank code path on fewer GPUs, not a measurement of xGMI)."""
     host = os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid")
     if not os.path.exists(host):      # (normally built by __graft_entry__.build(); a fresh checkout builds it here)
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "pi-sph-fluid_amd"), "all"], stdout=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "0"))
     scene = {"cfg2": "dam", "dam": "dam", "cfg3": "cfg3", "cfg4": "cfg4"}[args.workload]
-    cmd = [host, "--scene", scene, "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    cmd = [host, "--scene", scene, "--steps", str(args.steps), "--warmup", str(args.warmup), "--transport", args.transport]
     if args.workload == "cfg4":
         cmd.append("--tilt")
-    if world:          # torchrun started the ranks: this process is one of them
+    if world and args.transport == "rccl":          # torchrun started the ranks: this process is one of them
         rank = int(os.environ.get("RANK", "0"))
-        idfile = "/tmp/sph_bench_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        # one file per job: the launcher's run id (and port) name it; rank 0 removes it once every rank has joined
+        job = "%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "0"), os.getppid())
+        idfile = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sph_bench_%d_%s.id" % (os.getuid(), "".join(ch for ch in job if ch.isalnum() or ch in "_-")))
         cmd += ["--ranks", str(world), "--rank", str(rank), "--id-file", idfile]
+    elif world:                                     # (the shared-memory transport starts its own ranks: one launcher only)
+        rank = int(os.environ.get("RANK", "0"))
+        if rank != 0:
+            return
+        cmd += ["--ranks", str(world)]
     else:
         rank, world = 0, args.gpus
         cmd += ["--ranks", str(world)]
@@ -301,7 +341,11 @@ def run_c_host(sph, args):
     d = json.loads(lines[-1])
     n_total, tps = d["n_fluid"], d["ticks_per_s"]
     step_gbs = sph.STEP_ALGO_BYTES * n_total * tps / 1e9 / world
-    emit({
+    # the dominant kernel (the force pass, which also integrates) of rank 0's slab against the HBM roofline of ITS GPU:
+    # 80 algorithmic bytes per particle the launch covers (owned + ghosts), live duration from the C host
+    force_ms, n_loc = d.get("rank0_force_ms", 0.0), d.get("rank0_local", 0)
+    force_gbs = sph.KERNEL_ALGO_BYTES["force_kick"] * n_loc / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None
+    out = {
         "metric": "SPH Mparticle-steps/sec (N_fluid x timesteps/sec / 1e6)",
         "value": round(d["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s", "timesteps_per_s": round(tps, 2),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": d["ms_per_step"],
@@ -310,13 +354,20 @@ def run_c_host(sph, args):
         "config": {"workload": "%s: %d fluid + %d boundary particles" % (d["workload"], n_total, d["n_boundary"]),
                    "n_fluid": n_total, "n_boundary": d["n_boundary"],
                    "parallelism": "%d x-slabs, one process per GPU, C host (slab_sph_fluid): 2-column halo + migration in one "
-                                  "ncclSend/ncclRecv pair per neighbour per step, 4-byte ncclAllReduce(max) of the rebuild word" % world},
+                                  "%s per neighbour per step, %s of the rebuild word" %
+                                  (world, "ncclSend/ncclRecv pair" if args.transport == "rccl" else "shared-memory mailbox (REHEARSAL transport: the ranks may share a GPU)",
+                                   "4-byte ncclAllReduce(max)" if args.transport == "rccl" else "host max-reduction")},
         "particles_conserved": d["particles_conserved"],
         "neighbour_rebuilds_per_step": round(d["neighbour_rebuilds"] / max(args.steps + args.warmup, 1), 4),
-        "roofline": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s per GPU (whole step, 152 B per particle-step)", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
-                     "traffic": None},
-    })
+        "kernel_ms": {"density_eos": d.get("rank0_density_ms"), "force_kick": d.get("rank0_force_ms")},
+        "roofline": {"bound": "hbm", "kernel": "force_kick (rank 0's slab: %d particles incl. ghosts)" % n_loc,
+                     "achieved": round(force_gbs, 1) if force_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(force_gbs / HBM_PEAK_GBS, 4) if force_gbs else None, "traffic": None,
+                     "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                     "step_unit": "GB/s per GPU (whole step, 152 B per particle-step)"},
+        "cpu_baseline": cached_cpu_baseline(),      # measured by the N = 1 run on this host (None if there was none)
+    }
+    emit(out)
 
 
 def main():
@@ -327,9 +378,10 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--tilt", action="store_true", help="N = 1: gravity from the scripted tilt trace (cfg4 is defined with it)")
     ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "rccl"), choices=["rccl", "host"],
-                    help="N > 1: halo transport. rccl = torch.distributed nccl backend (RCCL over xGMI), one GPU per "
-                         "rank; host = host-staged gloo (rehearsal: all ranks may share one device)")
+                    help="N > 1: halo transport. rccl = RCCL over xGMI, one GPU per rank; host = host-staged (C host: POSIX "
+                         "shared memory; python host: gloo): a rehearsal, all ranks may share one device")
     ap.add_argument("--lib", default=None, help="A/B measurements: load this build of libsph_hip.so instead of the in-tree one")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin as a fraction of 2H (default: the library's)")
     ap.add_argument("--slab-host", default="c", choices=["c", "python"],
@@ -347,7 +399,7 @@ def main():
         sph.LIB_HIP = os.path.abspath(args.lib)
 
     slabbed = args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.slabs_on_one_gpu
-    if slabbed and args.slab_host == "c" and args.transport == "rccl":
+    if slabbed and args.slab_host == "c":
         quiet_stdout()
         run_c_host(sph, args)
         return
@@ -361,7 +413,7 @@ def main():
         run_slabs(sph, args, emit)
         return
 
-    res = run_single(sph, args.workload, args.steps, args.warmup, skin=args.skin)
+    res = run_single(sph, args.workload, args.steps, args.warmup, skin=args.skin, tilt=args.tilt)
     log("primary:", json.dumps(res))
     out = {
         "metric": "SPH Mparticle-steps/sec (N_fluid x timesteps/sec / 1e6)",
@@ -370,56 +422,56 @@ def main():
         "timesteps_per_s": round(res["steps_per_s"], 2),
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(res["ms_per_step"], 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": None, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d fluid + %d boundary particles, dam break, box %s" %
+        "config": {"workload": "%s: %d fluid + %d boundary particles, %s" %
                    (res["workload"], res["n_fluid"], res["n_boundary"],
-                    "1200 x 60 m" if res["workload"] == "cfg2" else "see SURVEY.md 8d"),
+                    "dam break, box 1200 x 60 m" if res["workload"] == "cfg2" else "see SURVEY.md 8d"),
                    "n_fluid": res["n_fluid"], "n_boundary": res["n_boundary"], "grid_cells": res["grid_cells"],
                    "parallelism": "1 GPU"},
         "kernel_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items()},
         "neighbour_rebuilds_per_step": round(res["timed_rebuilds_per_step"], 4), "skin_fraction_of_2h": round(res["skin_frac"], 4),
-        "roofline": roofline(sph, res),
+        "roofline": roofline(sph, res, "cfg2_developed" if args.workload == "cfg2" and args.warmup >= 3000 else None),
     }
-    if not args.no_also and args.workload != "cfg1":
-        r1 = run_single(sph, "cfg1", max(args.steps, 1), args.warmup, skin=args.skin)
-        log("also:", json.dumps(r1))
-        out["also"] = [{"workload": "cfg1: %d fluid + %d boundary, drop on dry surface, box 409.6 x 204.8 m" %
-                        (r1["n_fluid"], r1["n_boundary"]),
-                        "value": round(r1["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
-                        "timesteps_per_s": round(r1["steps_per_s"], 2), "ms_per_step": round(r1["ms_per_step"], 5),
-                        "kernel_ms": {k: round(v, 5) for k, v in r1["kernel_ms"].items()},
-                        "neighbour_rebuilds_per_step": round(r1["timed_rebuilds_per_step"], 4),
-                        "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r1["n_fluid"] * r1["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)}]
+
+    def also_entry(label, r, traffic_key):
+        """one secondary measurement in SURVEY.md 8(d)'s protocol: warm-up, then the MEDIAN of several windows — whatever
+        --steps says (the headline above is exactly --steps steps after --warmup)"""
+        rf = roofline(sph, r, traffic_key)
+        return {"workload": label, "protocol": "8d",
+                "protocol_detail": "%d warm-up steps, median of %d windows of %d steps" % (r["warmup"], r["windows"], r["window_steps"]),
+                "value": round(r["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
+                "timesteps_per_s": round(r["steps_per_s"], 2), "ms_per_step": round(r["ms_per_step"], 5),
+                "window_timesteps_per_s": r["window_steps_per_s"], "window_rebuilds_per_step": r["window_rebuilds_per_step"],
+                "kernel_ms": {k: round(v, 5) for k, v in r["kernel_ms"].items()},
+                "neighbour_rebuilds_per_step": round(r["timed_rebuilds_per_step"], 4),
+                "max_speed": round(r["max_speed"], 2), "device_mb": round(r["device_mb"], 1), "direct_tiles": r["direct_tiles"],
+                "step_frac": rf["step_frac"], "step_frac_executed": rf["step_frac_executed"], "roofline": rf}
+
     if not args.no_also and args.workload == "cfg2":
-        # the same scene once the flow is developed (splashes, |v| ~ 25 m/s): the neighbour structure is rebuilt three
-        # times as often as in the headline window
-        late_warm = 4000
-        r2 = run_single(sph, "cfg2", max(args.steps, 1), late_warm, skin=args.skin)
-        log("also:", json.dumps(r2))
-        out["also"].append({"workload": "cfg2, developed flow: steps %d-%d of the same run" % (late_warm, late_warm + args.steps),
-                            "value": round(r2["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
-                            "timesteps_per_s": round(r2["steps_per_s"], 2), "ms_per_step": round(r2["ms_per_step"], 5),
-                            "kernel_ms": {k: round(v, 5) for k, v in r2["kernel_ms"].items()},
-                            "neighbour_rebuilds_per_step": round(r2["timed_rebuilds_per_step"], 4),
-                            "max_speed": round(r2["max_speed"], 2),
-                            "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r2["n_fluid"] * r2["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)})
-    if not args.no_also and args.workload == "cfg2":
-        # cfg4 as BASELINE.json states it, on ONE GPU: 32 000 000 particles (7.4 GB of device memory: the HBM-resident
-        # point, nothing fits the 256 MiB Infinity Cache) under the scripted tilt trace
-        r4 = run_single(sph, "cfg4", max(min(args.steps, 200), 1), min(args.warmup, 50), profile_steps=5, skin=args.skin, tilt=True)
-        log("also:", json.dumps(r4))
-        out["also"].append({"workload": "cfg4 on one GPU: %d fluid + %d boundary, box 2400.6 x 150 m, scripted tilt gravity"
-                                        % (r4["n_fluid"], r4["n_boundary"]),
-                            "value": round(r4["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
-                            "timesteps_per_s": round(r4["steps_per_s"], 2), "ms_per_step": round(r4["ms_per_step"], 5),
-                            "kernel_ms": {k: round(v, 5) for k, v in r4["kernel_ms"].items()},
-                            "neighbour_rebuilds_per_step": round(r4["timed_rebuilds_per_step"], 4),
-                            "device_mb": round(r4["device_mb"], 1),
-                            "roofline_step_frac": round(sph.STEP_ALGO_BYTES * r4["n_fluid"] * r4["steps_per_s"] / 1e9 / HBM_PEAK_GBS, 4)})
+        out["also"] = []
+        # the headline scene itself, in the protocol: 200 warm-up steps, 5 windows of 1000
+        r = run_single(sph, "cfg2", 1000, 200, skin=args.skin, windows=5)
+        log("also:", json.dumps(r))
+        out["also"].append(also_entry("cfg2: %d fluid + %d boundary, dam break, box 1200 x 60 m" % (r["n_fluid"], r["n_boundary"]), r, "cfg2"))
+        r = run_single(sph, "cfg1", 1000, 200, skin=args.skin, windows=5)
+        log("also:", json.dumps(r))
+        out["also"].append(also_entry("cfg1: %d fluid + %d boundary, drop on dry surface, box 409.6 x 204.8 m" % (r["n_fluid"], r["n_boundary"]), r, "cfg1"))
+        # the same dam break once the flow is developed (splashes, |v| ~ 25 m/s): steps 4000 - 9000; the neighbour
+        # structure is rebuilt three times as often as in the first thousand steps
+        r = run_single(sph, "cfg2", 1000, 4000, skin=args.skin, windows=5)
+        log("also:", json.dumps(r))
+        out["also"].append(also_entry("cfg2, developed flow: steps 4000-9000 of the same run", r, "cfg2_developed"))
+        # cfg4 as BASELINE.json states it, on ONE GPU: 32 000 000 particles (6.8 GB of device memory: the HBM-resident
+        # point, nothing fits the 256 MiB Infinity Cache) under the scripted tilt trace; 3 windows of 200 steps (SURVEY 8d)
+        r = run_single(sph, "cfg4", 200, 50, profile_steps=5, skin=args.skin, tilt=True, windows=3)
+        log("also:", json.dumps(r))
+        out["also"].append(also_entry("cfg4 on one GPU: %d fluid + %d boundary, box 2400.6 x 150 m, scripted tilt gravity"
+                                      % (r["n_fluid"], r["n_boundary"]), r, "cfg4"))
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sph, args.workload)
-        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if out["cpu_baseline"]:
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     emit(out)
 
 

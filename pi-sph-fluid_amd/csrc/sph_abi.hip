@@ -1028,6 +1028,7 @@ int sph_slab_step_end(sph_ctx *ctx) {
     launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     ctx->velt_stale = fused(ctx);
     ctx->p_stale = true;
+    ctx->stepped = true;
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_overlapped = false;
     ctx->slab_phase = 0;

@@ -778,14 +778,22 @@ int main(int argc, char **argv) {
     }
     long long rebuilds = 0, direct = 0;
     sph_rebuild_stats(rs.ctx, &rebuilds, &direct);
+    /* the two heavy kernels of this rank's slab, back to back on the live state (HIP events on the context's stream): what
+     * bench.py prices against the HBM roofline */
+    float dens_ms = 0, force_ms = 0;
+    if (steps + warmup > 0) {
+        SPHCHK(rs.ctx, sph_time_kernel(rs.ctx, SPH_K_DENSITY_EOS, 20, &dens_ms));
+        SPHCHK(rs.ctx, sph_time_kernel(rs.ctx, SPH_K_FORCE_KICK, 20, &force_ms));
+    }
     if (rank == 0) {
         const double tps = steps > 0 ? (double)steps / elapsed : 0.0;
         printf("{\"host\": \"slab_sph_fluid (C, %s)\", \"workload\": \"%s%s\", \"n_gpus\": %d, \"n_fluid\": %ld, \"n_boundary\": %ld, "
                "\"steps\": %d, \"warmup\": %d, \"ticks_per_s\": %.2f, \"mparticle_steps_per_s\": %.2f, \"ms_per_step\": %.5f, "
-               "\"neighbour_rebuilds\": %lld, \"rebalanced\": %d, \"max_owned\": %lld, \"max_rho\": %.3f, \"max_speed\": %.3f, \"particles_conserved\": %s}\n",
+               "\"neighbour_rebuilds\": %lld, \"rebalanced\": %d, \"max_owned\": %lld, \"max_rho\": %.3f, \"max_speed\": %.3f, "
+               "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s}\n",
                transport == TR_RCCL ? "RCCL" : "host-staged shared memory", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
                steps, warmup, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
-               owned_total == (long long)n_total ? "true" : "false");
+               n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false");
         fflush(stdout);
     }
     if (owned_total != (long long)n_total) { fprintf(stderr, "[rank %d] particles lost: %lld of %ld\n", rank, owned_total, n_total); return 1; }

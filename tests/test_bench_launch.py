@@ -77,3 +77,21 @@ def test_c_host_path_one_slab(sph):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["particles_conserved"] is True
+
+
+@pytest.mark.gpu
+def test_c_host_two_ranks_share_the_gpu_through_bench(sph):
+    """bench.py --gpus 2 --transport host: the C host's N > 1 step loop (two processes, POSIX shared memory between them) on
+    the one GPU of this box; the line carries the dominant kernel's roofline and the kernels' live durations"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "30",
+                        "--warmup", "10"], capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["particles_conserved"] is True and out["config"]["n_fluid"] == 4000000
+    assert out["scaling"] == "weak" and "shared-memory" in out["config"]["parallelism"]
+    assert out["roofline"]["kernel"].startswith("force_kick") and 0 < out["roofline"]["frac"] < 1
+    assert out["kernel_ms"]["force_kick"] > 0 and out["kernel_ms"]["density_eos"] > 0
+    assert "cpu_baseline" in out
