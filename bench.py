@@ -58,7 +58,7 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
-def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False, windows=1):
+def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False, windows=1, load_state=None, save_state=None):
     """`windows` timed windows of `steps` steps each of one scene on device 0, after `warmup` steps; returns a result dict
     (rates: the median window; windows = 1: exactly `steps` timed steps).  tilt: gravity from the scripted tilt trace
     (sph_gravity: 15 deg, 8 s period, re-sampled every 0.1 s of simulated time like the reference's 10 Hz poll,
@@ -85,8 +85,15 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
     ctx = sph.Context(prm, f, b, g0[0], g0[1], device=0)
     create_s = time.time() - t0
     del f
+    if load_state:          # a checkpoint (sph_read_particles + sph_read_accel of an earlier run): profiling a developed flow
+        ck = np.load(load_state)      # without stepping up to it under the profiler
+        ctx.upload_state(ck["particles"].view(sph.PARTICLE).reshape(-1))
+        ctx.upload_accel(ck["du"], ck["dv"])
     advance(warmup)
     ctx.sync()
+    if save_state:
+        du_, dv_ = ctx.read_accel()
+        np.savez(save_state, particles=ctx.read_particles(), du=du_, dv=dv_)
     rates, rebuilt = [], []
     for _ in range(windows):
         r0, _d = ctx.rebuild_stats()
@@ -378,6 +385,8 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--save-state", default=None, help="N = 1: write the state after the warm-up (particles + accelerations, .npz)")
+    ap.add_argument("--load-state", default=None, help="N = 1: start from a state written by --save-state (then --warmup, then the timed steps)")
     ap.add_argument("--tilt", action="store_true", help="N = 1: gravity from the scripted tilt trace (cfg4 is defined with it)")
     ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "rccl"), choices=["rccl", "host"],
                     help="N > 1: halo transport. rccl = RCCL over xGMI, one GPU per rank; host = host-staged (C host: POSIX "
@@ -413,7 +422,8 @@ def main():
         run_slabs(sph, args, emit)
         return
 
-    res = run_single(sph, args.workload, args.steps, args.warmup, skin=args.skin, tilt=args.tilt)
+    res = run_single(sph, args.workload, args.steps, args.warmup, skin=args.skin, tilt=args.tilt, load_state=args.load_state,
+                     save_state=args.save_state)
     log("primary:", json.dumps(res))
     out = {
         "metric": "SPH Mparticle-steps/sec (N_fluid x timesteps/sec / 1e6)",

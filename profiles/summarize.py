@@ -42,7 +42,8 @@ def main():
     lines = ["# rocprofv3 summary: %s" % os.path.basename(d.rstrip("/")), ""]
     ks = os.path.join(d, "trace", "trace_kernel_stats.csv")
     if os.path.exists(ks):
-        lines += ["## per-kernel time (`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-also --steps 300 --warmup 100`)", "",
+        desc = sys.argv[5] if len(sys.argv) > 5 else "--steps 300 --warmup 100"
+        lines += ["## per-kernel time (`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-also %s`)" % desc, "",
                   "| kernel | calls | avg us | % | min us | max us |", "|---|---|---|---|---|---|"]
         for n, c, a, p, mn, mx in kernel_stats(ks):
             lines.append("| %s | %d | %.2f | %.2f | %.2f | %.2f |" % (n, c, a, p, mn, mx))
@@ -55,7 +56,7 @@ def main():
                 merged[kn].update(cs)
     if merged:
         counters = sorted({c for cs in merged.values() for c in cs})
-        lines += ["## PMC counters, mean per dispatch (separate `--pmc` passes, 10 steps after 30 warm-up)", "",
+        lines += ["## PMC counters, mean per dispatch (separate `--pmc` passes: 10 steps after the warm-up of the regime; with a long warm-up only those dispatches are counted, `--kernel-iteration-range`)", "",
                   "| kernel | " + " | ".join(counters) + " |", "|---|" + "---|" * len(counters)]
         for kn in sorted(merged):
             lines.append("| %s | " % kn + " | ".join("%.4g" % merged[kn][c] if c in merged[kn] else "" for c in counters) + " |")
@@ -73,7 +74,7 @@ def main():
     # per-launch HBM traffic of the step kernels in bench.py's naming (read side doubled, see above)
     names = {"k_kick_drift<false>": "kick_drift", "k_key_hist<false>": "key_hist", "k_reorder": "reorder",
              "k_build_list": "build_list", "k_density_list<1, 0>": "density_eos", "k_force_list<2, 0>": "force_kick", "k_check": "check",
-             "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply"}
+             "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply", "k_rebuild<0>": "rebuild"}
     traffic = {}
     for kn, bn in names.items():
         cs = merged.get(kn, {})
