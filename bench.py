@@ -65,7 +65,7 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
     pi_sph_fluid.c:455-461), one sph_step call per step as the reference re-reads g every step (:632)."""
     prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
     if skin is not None:
-        prm.skin = skin
+        prm.skin = prm.skin_min = skin      # a fixed skin
     n = len(f)
     grav = sph.GravitySource(sph.GRAVITY_TILT, 9.81) if tilt else None
     dt_sim = float(np.float32(prm.dt))

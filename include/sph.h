@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 5
+#define SPH_ABI_VERSION 6
 
 typedef enum sph_error {
     SPH_OK = 0,
@@ -60,8 +60,9 @@ typedef struct sph_params {
     float eps;    /* 0.01   viscosity singularity guard        :332 */
     float k1;     /* 0.1    artificial pressure strength       :325 */
     float k2;     /* 0.2    artificial pressure reference q    :325 */
-    float skin;   /* 0.15   Verlet skin of the neighbour structure as a fraction of 2H (no reference counterpart: the
-                            reference rebuilds every step, :626 = skin 0).  Per context; see "neighbour-structure reuse" */
+    float skin;   /* 0.30   Verlet skin of the neighbour structure as a fraction of 2H (no reference counterpart: the
+                            reference rebuilds every step, :626 = skin 0): the LARGEST skin the lists are built with, and what
+                            the device grid is sized for (cell = 2H (1 + skin)).  Per context; see "neighbour-structure reuse" */
     int deterministic;   /* 0 (default): the particles of a grid cell are kept in the order in which the binning atomics
                             arrived, which differs from run to run (results agree to rounding: the summation order of a
                             particle's neighbours follows it).  1: in particle-id order (one more pass per rebuild, < 1 % of
@@ -70,6 +71,11 @@ typedef struct sph_params {
                             as long as both rebuild in the same steps (the order follows the cells at the last rebuild):
                             always with skin = 0; with a skin, a slab may rebuild a step earlier than a single context
                             would (waves next to ghost particles use the absolute criterion) */
+    float skin_min;      /* 0.12   the SMALLEST skin (ABI v5).  skin_min < skin: the skin adapts — every rebuild looks at how many
+                            steps the last lists lasted and builds the next ones with a larger skin when that was short (a violent
+                            flow: a rebuild costs more than two steps) and a smaller one when it was long (a calm flow: shorter
+                            lists, cheaper steps).  skin_min >= skin (or skin = 0): the skin is fixed at `skin`.  Results do not
+                            depend on the skin beyond summation order. */
 } sph_params;
 
 typedef struct sph_ctx sph_ctx;
@@ -160,7 +166,9 @@ int  sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell);
  * so a jet moving as a whole keeps its lists) and nobody has moved more than H + skin.  Until then no unlisted pair
  * can be inside the support 2H, and listed pairs beyond 2H contribute exactly 0.  Results do not depend on the skin
  * (beyond summation order).  skin = 0: a rebuild whenever neighbouring particles moved relative to each other at all.
- * The skin is sph_params.skin (a fraction of 2H, 0 <= skin <= 1), fixed per context at creation. */
+ * The skin is a fraction of 2H between sph_params.skin_min and sph_params.skin (0 <= skin <= 1), chosen by the device at
+ * every rebuild from how long the last lists lasted; skin_min >= skin fixes it.  sph_current_skin() reads it. */
+float sph_current_skin(sph_ctx *ctx);      /* the skin (fraction of 2H) the present lists were built with */
 /* cell length of the device grid for these parameters: 2H (1 + skin) — what slab hosts must bin with */
 float sph_device_cell(const sph_params *prm);
 /* ask for a rebuild of the neighbour structure in the next step whatever the displacement criterion says (measurement;

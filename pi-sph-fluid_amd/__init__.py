@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_set_boundary_velocity", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
     "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_get_rebuild_launches", "sph_rebuild_stats", "sph_check_stats",
-    "sph_direct_tile_reasons",
+    "sph_direct_tile_reasons", "sph_current_skin",
     "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
     "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
     "sph_render_metaballs",
@@ -61,7 +61,7 @@ class Params(C.Structure):
                 ("g", C.c_float), ("dt", C.c_float), ("vol", C.c_float),
                 ("x_min", C.c_float), ("x_max", C.c_float), ("y_min", C.c_float), ("y_max", C.c_float),
                 ("alpha", C.c_float), ("eps", C.c_float), ("k1", C.c_float), ("k2", C.c_float),
-                ("skin", C.c_float), ("deterministic", C.c_int)]
+                ("skin", C.c_float), ("deterministic", C.c_int), ("skin_min", C.c_float)]
 
 
 class KernelTimes(C.Structure):
@@ -144,6 +144,8 @@ def hip_lib():
         L.sph_rebuild_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.sph_check_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.sph_direct_tile_reasons.argtypes = [vp, C.POINTER(C.c_longlong)]
+        L.sph_current_skin.argtypes = [vp]
+        L.sph_current_skin.restype = C.c_float
         L.sph_upload_state.argtypes = [vp, vp]
         L.sph_upload_accel.argtypes = [vp, vp, vp]
         L.sph_eval_density.argtypes = [vp]
@@ -215,13 +217,14 @@ def host_lib():
 
 def default_params(box=None, skin=None, deterministic=False):
     """reference defaults (:11-20); box = (x_min, x_max, y_min, y_max); skin = Verlet skin as a fraction of 2H
-    (None: the library default; 0: rebuild the neighbour structure every step like the reference, :626)."""
+    (None: the library default, a skin that adapts between skin_min and skin; a number: that skin, fixed; 0: rebuild
+    the neighbour structure every step like the reference, :626)."""
     p = Params()
     host_lib().sph_params_default(C.byref(p))
     if box is not None:
         p.x_min, p.x_max, p.y_min, p.y_max = [float(v) for v in box]
     if skin is not None:
-        p.skin = float(skin)
+        p.skin = p.skin_min = float(skin)
     p.deterministic = 1 if deterministic else 0
     return p
 
@@ -449,6 +452,13 @@ class Context:
         a, b = C.c_longlong(), C.c_longlong()
         self._chk(self.L.sph_rebuild_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def current_skin(self):
+        """the skin of the present neighbour lists, as a fraction of 2H (it adapts between skin_min and skin)."""
+        s = float(self.L.sph_current_skin(self.h))
+        if s < 0:
+            raise SphError(SPH_E_HIP, "sph_current_skin failed")
+        return s
 
     def direct_tile_reasons(self):
         """why tiles went to the direct path so far: counts of (pairs, rows, runs / cell table, candidates, window, list length)."""

@@ -115,13 +115,11 @@ int make_consts(const sph_params &p, Consts &c) {
     c.inv_h = 1.0f / p.h;
     const float two_h = 2 * p.h;                                         // :144
     c.cut2 = two_h * two_h;
-    const float skin = skin_frac * two_h;
-    c.cut_list2 = (two_h + skin) * (two_h + skin);
-    c.lim2 = (0.5f * skin) * (0.5f * skin);
-    c.skin2 = skin * skin;
-    c.cap2 = (p.h + skin) * (p.h + skin);
-    if (skin > 0.0f) { c.lim2 *= 0.999f; c.skin2 *= 0.999f; }      // rounding of the squared distances stays on the safe side
-    c.cap2 *= 0.999f;
+    c.two_h = two_h;
+    const float skin = skin_frac * two_h;                                // the largest skin: what the grid is sized for
+    c.skin_max = skin;
+    c.skin_min = p.skin_min >= 0.0f && p.skin_min < skin_frac ? p.skin_min * two_h : skin;      // (>= skin: fixed)
+    c.cap2 = (p.h + skin) * (p.h + skin) * 0.999f;                       // (rounding of the squared distances stays on the safe side)
     c.nf = (float)nf;
     c.grad_c = (float)(5.0 * nf / (H * H));                              // :56-59
     const double q = p.k2;                                               // W(0.2 H): q = 0.2   :325
@@ -452,7 +450,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles * SCAN_SPREAD); ALLOC(a.bcell_start, pad); ALLOC(a.bnear, pad);
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
-    ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4);
+    ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4); ALLOC(a.dyn, DYN_COUNT);
     ALLOC(a.gbar, (size_t)GBAR_WORDS * GBAR_STRIDE);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 1024);
     ALLOC(ctx->d_ids, n);
@@ -491,6 +489,12 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         }
     const uint32_t hdn[4] = {(uint32_t)n_fluid, (uint32_t)n_fluid, 0u, 0u};
     HIPCHK(ctx, hipMemcpyAsync(a.dn, hdn, sizeof hdn, hipMemcpyHostToDevice, st));
+    {   // the skin the first lists are built with (adapt_skin derives the thresholds from it at the first rebuild): a
+        // third of the way from the smallest to the largest
+        const Consts &c = ctx->c;
+        const float hdyn[DYN_COUNT] = {0.0f, 0.0f, 0.0f, c.skin_min + (c.skin_max - c.skin_min) / 3.0f};
+        HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
+    }
 
     // boundary: bin once, pseudo-mass once (:600-601)
     std::vector<float2> hb(nb ? nb : 1), hbv(nb ? nb : 1);
@@ -737,6 +741,15 @@ float sph_device_cell(const sph_params *prm) {
     if (!prm || !(prm->skin >= 0.0f && prm->skin <= 1.0f)) return 0.0f;
     const float two_h = 2 * prm->h;
     return two_h + prm->skin * two_h;      // the arithmetic of make_consts
+}
+float sph_current_skin(sph_ctx *ctx) {
+    if (!ctx || !ctx->stream) return -1.0f;
+    (void)hipSetDevice(ctx->device);
+    float s = 0.0f;
+    if (hipMemcpyAsync(&s, ctx->a.dyn + DYN_SKIN, sizeof s, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return -1.0f;
+    return s / (2 * ctx->prm.h);
 }
 int sph_request_rebuild(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;

@@ -15,11 +15,12 @@ struct Consts {
     // kernel maths (pi_sph_fluid.c:45-62)
     float h, inv_h;          // H, 1/H
     float cut2;              // (2H)^2 : support test of :144 on squared distance
-    float cut_list2;         // (2H + skin)^2 : a pair enters a neighbour list below this distance (at rebuild time)
-    float lim2;              // (skin/2)^2 : while nobody is further than this from its rebuild position the lists are valid
-    float skin2;             // skin^2     : ... and beyond that, while neighbouring waves moved less than this RELATIVE to
-                             //              each other (k_check)
-    float cap2;              // (H+skin)^2 : ... and nobody is further than this from its rebuild position
+    // The skin of the neighbour lists is a device-side variable (Arrays::dyn, DYN_*): it adapts between skin_min and
+    // skin_max at every rebuild (adapt_skin).  The grid is sized for skin_max.
+    float two_h;             // 2H : the support radius (:144)
+    float skin_min, skin_max;   // [m]
+    float cap2;              // (H+skin_max)^2 : nobody may be further than this from its rebuild position (the walks that use
+                             //              no lists look at 5x5 sort cells / 3x3 wall cells around it)
     float nf;                // 7/(4 pi H^2)          :46
     float grad_c;            // 5 nf / H^2 : -dW/dq / (d H) = grad_c * (1-q/2)^3   (:56-59 with q/d = 1/H)
     float inv_w_k2h;         // 1 / W(0.2 H)          :325
@@ -97,6 +98,7 @@ struct Arrays {
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
+    float *dyn;         // DYN_COUNT floats: the list cut-off and the rebuild thresholds that follow from the current skin
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
     // slab halo buffers: uint32 header[4] = {count,..} + halo_cap records of 5 words (x, y, u, v, id)
     uint32_t *send[2], *recv[2];   // [0] = left neighbour, [1] = right neighbour
@@ -120,8 +122,23 @@ enum {
                             // the first and last own row than the bitmap holds, (2) more runs or cell-table entries than fit,
                             // (3) more candidates than the LDS tile holds, (4) a window no byte can index, (5) a list longer than LROWS
     FLAG_OFF_XCD = 19,      // workgroups of one-launch rebuilds so far that did not run on the XCD of their barrier leader
-    FLAG_COUNT = 20
+    FLAG_STEP = 20,         // steps so far (k_check counts them)
+    FLAG_LAST_REBUILD = 21, // FLAG_STEP at the last rebuild
+    FLAG_COUNT = 22
 };
+// Arrays::dyn
+enum {
+    DYN_CUT_LIST2 = 0,      // (2H + skin)^2 : a pair enters a neighbour list below this distance (at rebuild time)
+    DYN_LIM2 = 1,           // (skin/2)^2 : while nobody is further than this from its rebuild position the lists are valid
+    DYN_SKIN2 = 2,          // skin^2     : ... and beyond that, while neighbouring waves moved less than this RELATIVE to each other (k_check)
+    DYN_SKIN = 3,           // the skin [m] of the present lists
+    DYN_COUNT = 4
+};
+// the rebuild word: 0 = no rebuild; REBUILD_CRITERION = the displacement criterion asked for it (the interval since the last
+// rebuild then steers the skin); REBUILD_HOST = the host did (creation, upload, sph_request_rebuild: says nothing about the flow)
+enum { REBUILD_CRITERION = 1, REBUILD_HOST = 2 };
+// skin controller: lists that lasted fewer steps than ADAPT_SHORT get a larger skin next time, more than ADAPT_LONG a smaller
+constexpr int ADAPT_SHORT = 10, ADAPT_LONG = 20;
 constexpr int TILE_WORDS = 32;           // 32-bit words per tile record
 constexpr int WNBR_WORDS = 12;           // words per box group in Arrays::wnbr
 #ifndef SPH_BOX_GROUP

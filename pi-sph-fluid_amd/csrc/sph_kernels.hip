@@ -90,10 +90,10 @@ void launch_set_gravity(hipStream_t st, const Arrays &a, float gx, float gy) {
 
 __global__ void k_set_word(uint32_t *word, uint32_t value) { *word = value; }
 void launch_request_rebuild(hipStream_t st, const Arrays &a) {
-    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, 1u);
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, (uint32_t)REBUILD_HOST);
 }
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
-    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, on ? 1u : 0u);
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, on ? (uint32_t)REBUILD_HOST : 0u);
     if (!on) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.check, 0u);
 }
 
@@ -127,10 +127,10 @@ DEV float group_max(float v) {
 // boxes cover the owned particles only); group = the wave's box group (tile * 4 + wave of the tile: sph_list.inc).  A group
 // without a live lane leaves an empty box (zero displacement): in slab mode k_check may look at it (see there).
 DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group, float4 *__restrict__ wbox,
-                       uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild) {
+                       uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild, const float *__restrict__ dyn) {
     static_assert(BOXG == 64, "a box group is a wave");
     const float d2 = fmaf(ux, ux, uy * uy);
-    const bool over = live && !(d2 <= c.lim2);      // true for NaN too
+    const bool over = live && !(d2 <= dyn[DYN_LIM2]);      // true for NaN too
     const bool capped = live && !(d2 <= c.cap2);
     const float inf = __builtin_huge_valf();
     const float x0 = group_min(live ? ux : inf), y0 = group_min(live ? uy : inf);
@@ -139,7 +139,7 @@ DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group
     if ((threadIdx.x & 63) == 0) {
         wbox[group] = any_live != 0ull ? make_float4(x0, y0, x1, y1) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (any_over != 0ull) *check = 1u;
-        if (any_cap != 0ull) *rebuild = 1u;
+        if (any_cap != 0ull) atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);
     }
 }
 
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
                                                     float2 *__restrict__ vel, const uint32_t *__restrict__ cs,
                                                     const uint2 *__restrict__ lrec, float4 *__restrict__ wbox,
                                                     uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild,
-                                                    const uint32_t *__restrict__ dn) {
+                                                    const uint32_t *__restrict__ dn, const float *__restrict__ dyn) {
     // slab mode: only the OWNED range of the sorted arrays moves (cell_start of the last rebuild); the ghosts are
     // refreshed from their owners by the halo exchange of this step
     const int n = (int)dn[0];
@@ -175,14 +175,14 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
         ux = p.x - r.x;
         uy = p.y - r.y;
     }
-    drift_verdict(c, ux, uy, live, t / BOXG, wbox, check, rebuild);
+    drift_verdict(c, ux, uy, live, t / BOXG, wbox, check, rebuild, dyn);
 }
 
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab) {
     if (cap <= 0) return;
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
-    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn);
-    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn);
+    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn, a.dyn);
+    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn, a.dyn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -204,14 +204,39 @@ DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, ui
     }
 }
 
+// The skin of the next lists, chosen by ONE thread when a rebuild begins (the binning is its first phase).  The lists
+// that are being replaced lasted `interval` steps: fewer than ADAPT_SHORT -> a rebuild (which costs what two to three
+// steps cost) comes too often: a quarter more skin; more than ADAPT_LONG -> the lists are longer than they need be: a
+// tenth less.  Measured on the 2M-particle dam break with fixed skins: the best skin is 0.15 - 0.19 x 2H while the fluid is
+// at rest and 0.30 in the developed flow; a rebuild the host asked for says nothing about the flow and leaves the skin alone.
+// Everything that depends on the skin is written here: the list cut-off (build_tile), the two thresholds of the rebuild
+// criterion (drift_verdict, k_check).
+DEV void adapt_skin(const Consts &c, const uint32_t word, uint32_t *__restrict__ flags, float *__restrict__ dyn) {
+    const uint32_t step = flags[FLAG_STEP], last = flags[FLAG_LAST_REBUILD];
+    float skin = dyn[DYN_SKIN];
+    if (c.skin_min < c.skin_max && word == (uint32_t)REBUILD_CRITERION && last != 0u) {
+        const uint32_t interval = step - last;
+        if (interval < (uint32_t)ADAPT_SHORT) skin *= 1.25f;
+        else if (interval > (uint32_t)ADAPT_LONG) skin *= 0.9f;
+    }
+    skin = fminf(fmaxf(skin, c.skin_min), c.skin_max);
+    flags[FLAG_LAST_REBUILD] = step;
+    dyn[DYN_SKIN] = skin;
+    dyn[DYN_CUT_LIST2] = (c.two_h + skin) * (c.two_h + skin);
+    // (rounding of the squared distances stays on the safe side)
+    dyn[DYN_LIM2] = (0.5f * skin) * (0.5f * skin) * (skin > 0.0f ? 0.999f : 1.0f);
+    dyn[DYN_SKIN2] = skin * skin * (skin > 0.0f ? 0.999f : 1.0f);
+}
+
 template <bool SLAB>
 DEV void key_hist_body(const Consts &c, const float2 *__restrict__ pos, const uint32_t *__restrict__ id,
                        const float2 *__restrict__ vsrc, const uint32_t *__restrict__ cs, float2 *__restrict__ velk,
                        float4 *__restrict__ pk, uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
                        uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags, uint32_t *__restrict__ dn,
                        uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r, int chunk,
-                       uint32_t *__restrict__ block_sums) {
+                       uint32_t *__restrict__ block_sums, float *__restrict__ dyn, const uint32_t word) {
     const int t = chunk * BLK + threadIdx.x;      // chunk = 256 consecutive array slots
+    if (t == 0) adapt_skin(c, word, flags, dyn);  // a rebuild begins: the skin of the lists it will build
     const int lane = threadIdx.x & 63;
     int src0 = 0, n;
     if (SLAB) {
@@ -290,24 +315,28 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
                                                   uint32_t *__restrict__ slot, uint32_t *__restrict__ count,
                                                   uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
                                                   const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
-                                                  int nchunks, uint32_t *__restrict__ block_sums) {
-    if (*rebuild == 0u) return;      // rebuild kernel
+                                                  int nchunks, uint32_t *__restrict__ block_sums, float *__restrict__ dyn) {
+    const uint32_t word = *rebuild;
+    if (word == 0u) return;      // rebuild kernel
     // a small grid striding over the chunks: in most steps this launch returns at once, and what that costs grows with
     // the grid (1.5 us up to 2048 workgroups, 2.8 us at 8192: tools/ubench_launch)
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x)
-        key_hist_body<false>(c, pos, id, vsrc, cs, velk, pk, slot, count, dirty, flags, dn, nullptr, nullptr, chunk, block_sums);
+        key_hist_body<false>(c, pos, id, vsrc, cs, velk, pk, slot, count, dirty, flags, dn, nullptr, nullptr, chunk, block_sums, dyn, word);
 }
 
 // the pair part of criterion (1): every box group against every group k_build_list listed for it, eight threads per group
 // (one per range of groups, two idle: the loads of a group are a chain of dependent latencies when one thread does them all)
 constexpr int CHECK_LANES = 8;
 DEV void check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr, uint32_t *__restrict__ rebuild,
-                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe);
+                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn);
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                                                const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
                                                uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
                                                const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
-                                               uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy) {
+                                               uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy,
+                                               const float *__restrict__ dyn) {
+    // the first kernel of every step: it counts them (the skin controller measures how many steps a set of lists lasted)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_STEP], 1u);
     // (slab mode: the gravity of this step rides along instead of taking a launch of its own)
     if (grav && blockIdx.x == 0 && threadIdx.x == 0) *grav = make_float2(gx, gy);
     // slab mode: this is the first kernel of a step; it also clears the headers of the send buffers (count, kind) for
@@ -329,10 +358,11 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
     }
     // (a small grid striding over the groups: see k_key_hist)
     for (int t = blockIdx.x * BLK + threadIdx.x; t < nw * CHECK_LANES; t += gridDim.x * BLK)
-        check_group(c, wbox, wnbr, rebuild, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi, own_safe);
+        check_group(c, wbox, wnbr, rebuild, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi, own_safe, dyn);
 }
 DEV void check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr, uint32_t *__restrict__ rebuild,
-                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe) {
+                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn) {
+    const float skin2 = dyn[DYN_SKIN2];
     if (w * BOXG >= own_hi || (w + 1) * BOXG <= own_lo) return;      // no owned particle in this group
     const float4 b = wbox[w];
     const uint32_t *nb = wnbr + (size_t)w * WNBR_WORDS;
@@ -348,30 +378,37 @@ DEV void check_group(const Consts &c, const float4 *__restrict__ wbox, const uin
     bool bad = false;
     if (meets_ghosts) {
         const float mx = fmaxf(fabsf(b.x), fabsf(b.z)), my = fmaxf(fabsf(b.y), fabsf(b.w));
-        bad = k == 0 && !(fmaf(mx, mx, my * my) <= c.lim2);
+        bad = k == 0 && !(fmaf(mx, mx, my * my) <= dyn[DYN_LIM2]);
     } else if (k < WNBR_WORDS / 2) {
         const uint32_t first = nb[2 * k], last = nb[2 * k + 1];
-        for (uint32_t o = first; o <= last && o != 0xffffffffu; o++) {      // first > last: nobody in that pair
-            const float4 q = wbox[o];
-            const float rx = fmaxf(b.z - q.x, q.z - b.x), ry = fmaxf(b.w - q.y, q.w - b.y);
-            bad |= !(fmaf(rx, rx, ry * ry) <= c.skin2);
+        // (first > last: nobody in that range.  Four boxes per trip, their loads in flight together: one by one they are
+        // a chain of memory latencies, and this kernel is nothing but latency)
+        for (uint32_t o = first; o <= last && o != 0xffffffffu; o += 4u) {
+            float4 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = wbox[min(o + (uint32_t)j, last)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float rx = fmaxf(b.z - q[j].x, q[j].z - b.x), ry = fmaxf(b.w - q[j].y, q[j].w - b.y);
+                bad |= !(fmaf(rx, rx, ry * ry) <= skin2);
+            }
         }
     }
-    if (bad) *rebuild = 1u;
+    if (bad) atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);      // (never lowers a host's request)
 }
 void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity) {
     if (cap <= 0) return;
     const int nw = (cap + BOXG - 1) / BOXG;
     hipLaunchKernelGGL(k_check, dim3(gated_grid((nw * CHECK_LANES + BLK - 1) / BLK)), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check,
                        a.rebuild, a.flags, a.dn, a.send[0], a.send[1], nw, gravity ? a.grav : nullptr, gravity ? gravity[0] : 0.0f,
-                       gravity ? gravity[1] : 0.0f);
+                       gravity ? gravity[1] : 0.0f, a.dyn);
 }
 
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc) {
     if (cap <= 0) return;
     const int nchunks = (cap + BLK - 1) / BLK;
     hipLaunchKernelGGL(k_key_hist, dim3(gated_grid(nchunks)), dim3(BLK), 0, st, c, a.pos, a.id, vsrc, a.cell_start, a.velk,
-                       a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, nchunks, a.block_sums);
+                       a.pk, a.slot, a.count, a.dirty, a.flags, a.rebuild, a.dn, nchunks, a.block_sums, a.dyn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -422,11 +459,13 @@ __global__ __launch_bounds__(BLK) void k_halo_out(Consts c, const float2 *__rest
                                                   uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
                                                   const uint32_t *__restrict__ rebuild, uint32_t *__restrict__ dn,
                                                   uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r,
-                                                  int part_blocks, int halo_blocks, uint32_t *__restrict__ block_sums) {
+                                                  int part_blocks, int halo_blocks, uint32_t *__restrict__ block_sums,
+                                                  float *__restrict__ dyn) {
     // (a small grid striding over the work: on most steps only the two update packs run; see k_key_hist)
-    if (*rebuild != 0u) {
+    const uint32_t word = *rebuild;
+    if (word != 0u) {
         for (int vb = (int)blockIdx.x; vb < part_blocks; vb += (int)gridDim.x)
-            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r, vb, block_sums);
+            key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r, vb, block_sums, dyn, word);
     } else {
         for (int vb = (int)blockIdx.x; vb < 2 * halo_blocks; vb += (int)gridDim.x) {
             const int side = vb / halo_blocks;
@@ -440,7 +479,7 @@ void launch_halo_out(hipStream_t st, const Consts &c, const Arrays &a, int cap) 
     const int part_blocks = (cap + BLK - 1) / BLK, halo_blocks = (c.halo_cap + BLK - 1) / BLK;
     const int grid = part_blocks > 2 * halo_blocks ? part_blocks : 2 * halo_blocks;
     hipLaunchKernelGGL(k_halo_out, dim3(gated_grid(grid)), dim3(BLK), 0, st, c, a.pos, a.id, a.vel, a.cell_start, a.velk, a.pk, a.slot,
-                       a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1], part_blocks, halo_blocks, a.block_sums);
+                       a.count, a.dirty, a.flags, a.rebuild, a.dn, a.send[0], a.send[1], part_blocks, halo_blocks, a.block_sums, a.dyn);
 }
 
 // slab mode, rebuild step, after the scatter: put every cell of the interface columns (two ghost + two owned columns

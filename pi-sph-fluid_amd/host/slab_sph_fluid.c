@@ -605,7 +605,7 @@ int main(int argc, char **argv) {
     sph_params prm;
     sph_params_default(&prm);
     prm.deterministic = deterministic;
-    if (skin >= 0) prm.skin = skin;
+    if (skin >= 0) prm.skin = prm.skin_min = skin;      /* a fixed skin */
     prm.x_max = sc.box_w;
     prm.y_max = sc.box_h;
     const int cols = sph_slab_grid_columns(&prm);

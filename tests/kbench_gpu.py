@@ -15,7 +15,7 @@ if os.path.exists(ablate_lib):
     sph.LIB_HIP = ablate_lib
 prm, f, b = sph.dam_break(1)
 if len(sys.argv) > 2:
-    prm.skin = float(sys.argv[2])
+    prm.skin = prm.skin_min = float(sys.argv[2])
 os.environ.pop("SPH_ABLATE", None)
 ctx = sph.Context(prm, f, b)
 ctx.step(warm)

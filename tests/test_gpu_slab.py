@@ -109,7 +109,7 @@ def test_slab_reuses_lists_between_rebuilds(sph, orc):
     b = boundary_particles(orc, g["boundary_xy"])
     if True:
         for frac in (0.0, 0.2):
-            prm.skin = frac          # per context: the slabs and the single context below all get this skin
+            prm.skin = prm.skin_min = frac          # per context: the slabs and the single context below all get this skin
             slabs, runner = build(sph, prm, f, b, 3)
             with sph.Context(prm, f, b, GX, GY) as ctx:
                 ctx.step(20, GX, GY)

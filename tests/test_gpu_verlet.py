@@ -128,7 +128,7 @@ def test_fast_random_particles(sph, orc):
     f = particles(orc, state, m_fluid(prm))
     prm2, _, walls = sph.scene_disc(box, 8.0, 8.0, 0.1)
     for frac in (0.1, 0.3):
-        prm.skin = frac
+        prm.skin = prm.skin_min = frac
         with sph.Context(prm, f, walls, 0.0, 0.0) as ctx:
             for k in range(12):
                 ctx.step(3, 0.0, 0.0)
@@ -143,7 +143,7 @@ def test_coherent_motion_keeps_lists(sph, orc, oracle):
     rebuild every other step; the relative one (per-wave displacement boxes) keeps the lists for many steps.  Results
     against the oracle and against the exact walk as usual."""
     prm, f, b = sph.scene_block((0.0, 40.0, 0.0, 6.0), 2.0, 1.5, 160, 40)
-    prm.skin = 0.15
+    prm.skin = prm.skin_min = 0.15
     f["u"] = 30.0
     p = oracle.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
     of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()

@@ -22,12 +22,12 @@ def test_abi_library_loads_and_exports_every_declared_symbol(sph):
     hdecl = set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", hheader))
     for name in hdecl:
         assert hasattr(H, name), name
-    assert L.sph_abi_version() == 5
+    assert L.sph_abi_version() == 6
 
 
 def test_struct_layouts(sph):
     assert sph.PARTICLE.itemsize == 28                       # struct particle :26-31
-    assert C.sizeof(sph.Params) == 17 * 4
+    assert C.sizeof(sph.Params) == 18 * 4
     assert C.sizeof(sph.KernelTimes) == 8 * 4 + 4 + 4 + 4
 
 
@@ -127,7 +127,7 @@ def test_skin_is_a_per_context_parameter(sph):
     device cell 2H (1 + skin) of THEIR parameters (no process-wide state)."""
     L = sph.hip_lib()
     prm = sph.default_params()
-    assert abs(prm.skin - 0.15) < 1e-7
+    assert abs(prm.skin - 0.30) < 1e-7 and abs(prm.skin_min - 0.12) < 1e-7      # the largest and smallest skin
     two_h = np.float32(2) * np.float32(prm.h)
     for frac in (0.0, 0.1, 0.4):
         prm.skin = frac
@@ -138,7 +138,7 @@ def test_skin_is_a_per_context_parameter(sph):
         cols = sph.slab.grid_columns(prm)
         assert cols == int((np.float32(prm.x_max) - np.float32(prm.x_min)) / cell) + 1
     other = sph.default_params()                      # untouched by the loop above
-    assert abs(np.float32(L.sph_device_cell(C.byref(other))) - two_h * np.float32(1.15)) <= 2e-7
+    assert abs(np.float32(L.sph_device_cell(C.byref(other))) - two_h * np.float32(1.30)) <= 2e-7
     prm.skin = 1.5
     assert L.sph_device_cell(C.byref(prm)) == 0.0      # invalid
     _, f, b = sph.scene("cfg0")

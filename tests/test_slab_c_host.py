@@ -134,7 +134,7 @@ def _flying_block(sph, u=5.0, deterministic=True, skin=0.0):
     prm, f, b = sph.scene_block((0.0, 90.0, 0.0, 20.0), 0.3, 0.3, 600, 150)
     prm.deterministic = 1 if deterministic else 0
     if skin is not None:
-        prm.skin = skin
+        prm.skin = prm.skin_min = skin
     f["u"] = u
     return prm, f, b
 
