@@ -121,6 +121,7 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
            "steps_per_s": rates[mid], "ms_per_step": 1e3 / rates[mid],
            "mparticle_steps_per_s": rates[mid] * n / 1e6, "kernel_ms": kt,
            "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s, "skin_frac": float(prm.skin),
+           "skin_min_frac": float(min(prm.skin_min, prm.skin)), "skin_now": ctx.current_skin(),
            "rebuilds": rebuilds, "direct_tiles": direct_tiles, "timed_rebuilds_per_step": rebuilt[mid],
            "window_steps_per_s": [round(x, 2) for x in rates], "window_rebuilds_per_step": [round(x, 4) for x in rebuilt],
            "windows": windows, "window_steps": steps, "warmup": warmup,
@@ -441,6 +442,7 @@ def main():
                    "parallelism": "1 GPU"},
         "kernel_ms": {k: round(v, 5) for k, v in res["kernel_ms"].items()},
         "neighbour_rebuilds_per_step": round(res["timed_rebuilds_per_step"], 4), "skin_fraction_of_2h": round(res["skin_frac"], 4),
+        "skin_min_fraction_of_2h": round(res["skin_min_frac"], 4), "skin_at_end_fraction_of_2h": round(res["skin_now"], 4),
         "roofline": roofline(sph, res, "cfg2_developed" if args.workload == "cfg2" and args.warmup >= 3000 else None),
     }
 

@@ -71,11 +71,11 @@ typedef struct sph_params {
                             as long as both rebuild in the same steps (the order follows the cells at the last rebuild):
                             always with skin = 0; with a skin, a slab may rebuild a step earlier than a single context
                             would (waves next to ghost particles use the absolute criterion) */
-    float skin_min;      /* 0.12   the SMALLEST skin (ABI v5).  skin_min < skin: the skin adapts — every rebuild looks at how many
-                            steps the last lists lasted and builds the next ones with a larger skin when that was short (a violent
-                            flow: a rebuild costs more than two steps) and a smaller one when it was long (a calm flow: shorter
-                            lists, cheaper steps).  skin_min >= skin (or skin = 0): the skin is fixed at `skin`.  Results do not
-                            depend on the skin beyond summation order. */
+    float skin_min;      /* 0.12   the SMALLEST skin (ABI v6).  skin_min < skin: the skin adapts — every rebuild looks at how many
+                            steps the last lists lasted (how fast the flow uses up a skin) and picks the skin that minimises
+                            list-walking cost + rebuild cost per step for that rate: larger in a violent flow (a rebuild costs
+                            more than two steps), smaller in a calm one (shorter lists, cheaper steps).  skin_min >= skin (or
+                            skin = 0): the skin is fixed at `skin`.  Results do not depend on the skin beyond summation order. */
 } sph_params;
 
 typedef struct sph_ctx sph_ctx;

@@ -137,8 +137,11 @@ enum {
 // the rebuild word: 0 = no rebuild; REBUILD_CRITERION = the displacement criterion asked for it (the interval since the last
 // rebuild then steers the skin); REBUILD_HOST = the host did (creation, upload, sph_request_rebuild: says nothing about the flow)
 enum { REBUILD_CRITERION = 1, REBUILD_HOST = 2 };
-// skin controller: lists that lasted fewer steps than ADAPT_SHORT get a larger skin next time, more than ADAPT_LONG a smaller
-constexpr int ADAPT_SHORT = 10, ADAPT_LONG = 20;
+// skin controller (adapt_skin, sph_kernels.hip): cost of a rebuild / (2 x the list-dependent cost of a step at skin 0)
+#ifndef SPH_ADAPT_RATIO
+#define SPH_ADAPT_RATIO 5.0f
+#endif
+constexpr float ADAPT_RATIO = SPH_ADAPT_RATIO;
 constexpr int TILE_WORDS = 32;           // 32-bit words per tile record
 constexpr int WNBR_WORDS = 12;           // words per box group in Arrays::wnbr
 #ifndef SPH_BOX_GROUP

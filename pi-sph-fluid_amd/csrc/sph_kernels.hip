@@ -205,19 +205,27 @@ DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, ui
 }
 
 // The skin of the next lists, chosen by ONE thread when a rebuild begins (the binning is its first phase).  The lists
-// that are being replaced lasted `interval` steps: fewer than ADAPT_SHORT -> a rebuild (which costs what two to three
-// steps cost) comes too often: a quarter more skin; more than ADAPT_LONG -> the lists are longer than they need be: a
-// tenth less.  Measured on the 2M-particle dam break with fixed skins: the best skin is 0.15 - 0.19 x 2H while the fluid is
-// at rest and 0.30 in the developed flow; a rebuild the host asked for says nothing about the flow and leaves the skin alone.
-// Everything that depends on the skin is written here: the list cut-off (build_tile), the two thresholds of the rebuild
-// criterion (drift_verdict, k_check).
+// that are being replaced had the skin s0 (as a fraction of 2H) and lasted T steps, so the flow eats s0 / T of skin per
+// step (the rebuild criterion is a bound on relative displacements, which grow linearly until something hits them).  A
+// step with skin s costs about K (1 + s)^2 (the two list walkers: list length ~ area of the cut-off disc) plus R / T(s)
+// (a rebuild every T(s) = T s / s0 steps): minimal where  s^2 (1 + s) = (R / 2K) (s0 / T).  On paper R / 2K is 2.9 on
+// MI355X (a rebuild ~200 us, the part of density + force that scales with the lists ~35 us at s = 0, 2M particles; both
+// scale with the particle count); measured (tests/skin_sweep_gpu.py, variants with 2 / 2.9 / 4 / 5.5 / 8): 4 and above are
+// equally good and better than 2.9, hence ADAPT_RATIO = 5.  The next skin is half-way from the old one to that optimum, clamped to [skin_min,
+// skin_max] (the grid is sized for skin_max).  Measured on the 2M-particle dam break with FIXED skins: best 0.15 - 0.19
+// while most of the fluid is at rest, 0.30 in the developed flow.  A rebuild the host asked for says nothing about the
+// flow and leaves the skin alone.  Everything that depends on the skin is written here: the list cut-off (build_tile) and
+// the two thresholds of the rebuild criterion (drift_verdict, k_check).
 DEV void adapt_skin(const Consts &c, const uint32_t word, uint32_t *__restrict__ flags, float *__restrict__ dyn) {
     const uint32_t step = flags[FLAG_STEP], last = flags[FLAG_LAST_REBUILD];
     float skin = dyn[DYN_SKIN];
     if (c.skin_min < c.skin_max && word == (uint32_t)REBUILD_CRITERION && last != 0u) {
-        const uint32_t interval = step - last;
-        if (interval < (uint32_t)ADAPT_SHORT) skin *= 1.25f;
-        else if (interval > (uint32_t)ADAPT_LONG) skin *= 0.9f;
+        const float T = fmaxf((float)(step - last), 1.0f);
+        const float rhs = ADAPT_RATIO * (skin / c.two_h) / T;
+        float s = sqrtf(rhs);                                   // s^2 (1 + s) = rhs, Newton from s^2 = rhs
+#pragma unroll
+        for (int it = 0; it < 4; it++) s -= (s * s * (1.0f + s) - rhs) / (s * (2.0f + 3.0f * s) + 1e-12f);
+        skin = 0.5f * (skin + s * c.two_h);
     }
     skin = fminf(fmaxf(skin, c.skin_min), c.skin_max);
     flags[FLAG_LAST_REBUILD] = step;

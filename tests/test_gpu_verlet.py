@@ -49,12 +49,15 @@ def lists_vs_exact_walk(ctx, tag):
     assert np.max(np.hypot(adu - bdu, adv - bdv) / scale) <= 1e-4, tag
 
 
-@pytest.mark.parametrize("frac", [0.05, 0.15, 0.4])
+@pytest.mark.parametrize("frac", [0.05, 0.15, 0.4, None])
 def test_reused_lists_equal_exact_walk(sph, orc, frac):
+    """(None: the library default, a skin that adapts between skin_min and skin to how long the lists last)"""
     prm, f, b, g = block_scene(sph, orc, frac)
     with sph.Context(prm, f, b, GX, GY) as ctx:
         rows, cols, cell = ctx.device_grid()
-        assert abs(cell - 2 * prm.h * (1 + frac)) <= 1e-6
+        assert abs(cell - 2 * prm.h * (1 + prm.skin)) <= 1e-6      # the grid is sized for the largest skin
+        assert prm.skin_min - 1e-6 <= ctx.current_skin() <= prm.skin + 1e-6
+        skins = set()
         r0, _ = ctx.rebuild_stats()
         done = 0
         for k in (7, 60, 200, 400):
@@ -62,9 +65,13 @@ def test_reused_lists_equal_exact_walk(sph, orc, frac):
             done = k
             ctx.sync()
             lists_vs_exact_walk(ctx, (frac, k))
+            skins.add(round(ctx.current_skin(), 4))
         r1, direct = ctx.rebuild_stats()
         assert r1 - r0 < done, (r0, r1)              # the lists were reused (their validity: the checks above)
-        if frac <= 0.05:
+        assert all(prm.skin_min - 1e-4 <= v <= prm.skin + 1e-4 for v in skins), skins
+        if frac is not None:
+            assert skins == {round(frac, 4)}, skins  # a fixed skin stays
+        if frac is not None and frac <= 0.05:
             assert r1 - r0 > 0, (r0, r1)             # a thin skin cannot survive 400 steps of a collapsing dam
         assert direct == 0
 
@@ -81,7 +88,7 @@ def test_skin_zero_rebuilds_every_step(sph, orc):
         assert kt["rebuilds_per_step"] == 1.0
 
 
-@pytest.mark.parametrize("frac", [0.0, 0.15, 0.4])
+@pytest.mark.parametrize("frac", [0.0, 0.15, 0.4, None])
 def test_trajectory_does_not_depend_on_skin(sph, orc, oracle, frac):
     """300 steps of the 14 400-particle dam break against the oracle, and the default scene against the golden
     trajectory (G5), under different skins."""
@@ -136,6 +143,37 @@ def test_fast_random_particles(sph, orc):
                 lists_vs_exact_walk(ctx, (frac, k))
             got = ctx.read_particles()
             assert np.all(np.isfinite(got["x"])) and np.all(np.isfinite(got["rho"]))
+
+
+def test_skin_controller(sph, orc):
+    """the default skin adapts to how long the lists last (adapt_skin, csrc/sph_kernels.hip): particles that cross a
+    skin within a few steps drive it up to sph_params.skin, a tank at rest lets it shrink towards skin_min; the lists stay
+    exact throughout (they are checked against the exact walk)."""
+    rng = np.random.default_rng(11)
+    box = (0.0, 16.0, 0.0, 16.0)
+    prm = sph.default_params(box)
+    assert prm.skin_min < prm.skin
+    side = 70
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    xy = 5.4 + 0.075 * np.stack([gx.ravel(), gy.ravel()], 1) + rng.uniform(-0.02, 0.02, (side * side, 2))
+    uv = rng.uniform(-40.0, 40.0, (side * side, 2)) * (rng.random((side * side, 1)) < 0.2)
+    f = particles(orc, np.concatenate([xy, uv], 1).astype(np.float32), m_fluid(prm))
+    _, _, walls = sph.scene_disc(box, 8.0, 8.0, 0.1)
+    with sph.Context(prm, f, walls, 0.0, 0.0) as ctx:
+        s0 = ctx.current_skin()
+        assert prm.skin_min < s0 < prm.skin
+        ctx.step(40, 0.0, 0.0)
+        ctx.sync()
+        lists_vs_exact_walk(ctx, "gas")
+        assert abs(ctx.current_skin() - prm.skin) <= 1e-6, ctx.current_skin()
+    prm, f, b = sph.scene_block((0.0, 30.6, 0.0, 8.0), 0.3, 0.3, 400, 60)      # a tank filled wall to wall: at rest
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.step(650, GX, GY)      # (lists last > 150 steps here; later this tank starts to slosh)
+        ctx.sync()
+        lists_vs_exact_walk(ctx, "tank")
+        r, direct = ctx.rebuild_stats()
+        assert ctx.current_skin() < s0 - 1e-3, (ctx.current_skin(), r)
+        assert direct == 0
 
 
 def test_coherent_motion_keeps_lists(sph, orc, oracle):
