@@ -460,6 +460,18 @@ def main():
                 "max_speed": round(r["max_speed"], 2), "device_mb": round(r["device_mb"], 1), "direct_tiles": r["direct_tiles"],
                 "step_frac": rf["step_frac"], "step_frac_executed": rf["step_frac_executed"], "roofline": rf}
 
+    if not args.no_also and args.workload == "cfg2" and args.skin is None and not args.load_state:
+        # The same window with the skin FIXED at round 2's 0.15 x 2H: the like-for-like figure for the two list walkers
+        # (the adaptive skin of the headline is near 0.30 at the end of the window: longer lists, fewer rebuilds, a faster
+        # step but slower kernels — their times in `roofline` / `kernel_ms` above are at THAT skin).
+        r = run_single(sph, "cfg2", args.steps, args.warmup, skin=0.15)
+        log("fixed skin:", json.dumps(r))
+        rf = roofline(sph, r, "cfg2_fixed_skin_0.15")
+        out["kernels_at_fixed_skin_0.15"] = {
+            "what": "the headline window (same steps, same warm-up) with sph_params.skin = skin_min = 0.15, round 2's setting",
+            "timesteps_per_s": round(r["steps_per_s"], 2), "neighbour_rebuilds_per_step": round(r["timed_rebuilds_per_step"], 4),
+            "density_eos_ms": round(r["kernel_ms"]["density_eos"], 5), "force_kick_ms": round(r["kernel_ms"]["force_kick"], 5),
+            "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algo_bytes_per_launch", "kernel_ms")}}
     if not args.no_also and args.workload == "cfg2":
         out["also"] = []
         # the headline scene itself, in the protocol: 200 warm-up steps, 5 windows of 1000

@@ -78,7 +78,7 @@ int main(int argc, char **argv) {
     sph_params prm;
     sph_params_default(&prm);
     prm.deterministic = deterministic;
-    if (skin >= 0) prm.skin = skin;
+    if (skin >= 0) prm.skin = prm.skin_min = skin;      /* a fixed skin */
     long n_fluid = 0, n_boundary = 0;
     sph_particle *fluid = NULL, *boundary = NULL;
     int accumulate = 0;
