@@ -248,6 +248,8 @@ int  sph_get_rebuild_launches(const sph_ctx *ctx);      /* 1: one launch, 0: one
  *     sph_slab_step_pack()    fills the send buffers (kind 0 or 1 according to the word)
  *     -- move send_right -> right neighbour's recv_left, send_left -> left neighbour's recv_right --
  *     sph_slab_step_overlap() optional, while the buffers move: density of the tiles that stage no ghost particle
+ *                             (or sph_slab_step_overlap_on(): the same on a stream of the host's, from right after
+ *                             sph_slab_step_begin — beside the reduction of the word too)
  *     sph_slab_step_end()     ingest + sort + lists (kind 0) or ghost update (kind 1), density + EOS + force + kick (:626-640) */
 typedef struct sph_slab_desc {
     int col_begin, col_end;      /* owned global cell columns [begin, end), at least 4 */
@@ -264,6 +266,12 @@ int  sph_create_slab(sph_ctx **out, const sph_params *prm, const sph_slab_desc *
 int  sph_slab_step_begin(sph_ctx *ctx, float gx, float gy);
 int  sph_slab_step_pack(sph_ctx *ctx);
 int  sph_slab_step_overlap(sph_ctx *ctx);
+/* The interior density pass on `hip_stream` (a hipStream_t of the caller's on the context's device; NULL = the context's
+ * own stream) at any point after sph_slab_step_begin: it needs the drifted positions and nothing of this step's halo.
+ * The CALLER orders the streams: `hip_stream` must wait for what sph_slab_step_begin enqueued on the context's stream
+ * (an event), and the context's stream must wait for this pass before sph_slab_step_end.  The pass reads the rebuild word
+ * as it finds it (reduced or not): on a step that turns out to rebuild its work is discarded, never wrong. */
+int  sph_slab_step_overlap_on(sph_ctx *ctx, void *hip_stream);
 int  sph_slab_step_end(sph_ctx *ctx);
 /* the rebuild word: its device address (library-owned unless replaced), adopting a word of the host framework
  * (e.g. a 1-element int32 torch tensor handed to RCCL; NULL = back to the library's own), host-staged access */

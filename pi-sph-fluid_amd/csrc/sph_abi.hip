@@ -1023,6 +1023,17 @@ int sph_slab_step_overlap(sph_ctx *ctx) {
     return SPH_OK;
 }
 
+int sph_slab_step_overlap_on(sph_ctx *ctx, void *hip_stream) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (!ctx->slab || ctx->slab_phase < 1) return fail(ctx, SPH_E_STATE, "sph_slab_step_overlap_on without sph_slab_step_begin");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_INTERIOR, false);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->slab_overlapped = true;
+    return SPH_OK;
+}
+
 int sph_slab_step_end(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     if (!ctx->slab || ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_step_end without sph_slab_step_pack");

@@ -23,7 +23,8 @@
  *
  *   slab_sph_fluid --ranks N [--transport rccl|host] [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--origin X0 Y0]
  *                  [--velocity U V] [--steps K] [--warmup W] [--tilt] [--check] [--deterministic] [--skin F]
- *                  [--rebalance-every K] [--capacity N] [--console] [--frame FILE] [--dump-state FILE]
+ *                  [--rebalance-every K] [--capacity N] [--console] [--frame FILE] [--dump-state FILE] [--selfcomm]
+ *                  [--exchange-stream serial|main|side]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
  * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
  * what may sit under a profiler; the launcher must not: see profiles/README.md).  The ncclUniqueId travels through a file
@@ -32,6 +33,15 @@
  * fixed 8M / 32M scenes; --tilt: gravity from the scripted tilt trace (sph_gravity, the MPU6050 stand-in), sampled every
  * step with its 0.1 s hold.  Every rank generates only the lattice columns it holds.
  * --check (N = 1): the run is repeated with sph_step on a single context and the two final states are compared.
+ * --exchange-stream (rccl): where the RCCL calls of a step go.  serial (default) = all-reduce, pack, send / receive and
+ * everything else on ONE stream, nothing beside anything; main = the same, with the interior density pass on a side stream
+ * from right after sph_slab_step_begin; side = the exchange on the side stream with the interior density pass beside it on
+ * the main stream (round 2's order).  Measured with --selfcomm on one MI355X (us per step; 95-101 without any RCCL call):
+ * serial 113-114, main 131-137, side 139-144 — a stream that is already waiting when the event it waits for fires resumes
+ * ~13-15 us later, and the two overlapping orders pay that twice per step (fork and join), which is more than the ~15 us
+ * send / receive kernel they hide; that kernel also takes twice as long (31 us) beside a density pass.
+ * --selfcomm (N = 1, rccl; a measurement): the all-reduce and the grouped send / receive of every step are issued anyway,
+ * to this rank itself: what the RCCL calls of a step cost (enqueue + their kernels) before any neighbour is waited for.
  */
 #define _GNU_SOURCE
 #define __HIP_PLATFORM_AMD__ 1
@@ -96,6 +106,8 @@ typedef struct comm {
     unsigned long seq;            /* collectives so far (parity: which of the two slots / mailboxes) */
     unsigned long xseq;           /* all-to-all exchanges so far (names of their segments) */
     size_t coll_bytes, halo_bytes;
+    int selfcomm;                 /* measurement (--selfcomm, one rank, rccl): the step's RCCL calls made anyway, to itself */
+    int serial;                   /* --exchange-stream: 2 = serial (default), 0 = main, 1 = side */
 } comm;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -193,7 +205,7 @@ static int comm_allreduce(comm *cm, void *buf, size_t count, int op) {
 
 /* the rebuild word of this step, MAX-reduced over the ranks, on the context's stream */
 static int comm_reduce_word(comm *cm, sph_ctx *ctx, void *dev_word, hipStream_t st) {
-    if (cm->nranks == 1) return 0;
+    if (cm->nranks == 1 && !(cm->selfcomm && cm->kind == TR_RCCL)) return 0;
     if (cm->kind == TR_RCCL) {
         NCCLCHK(ncclAllReduce(dev_word, dev_word, 1, ncclUint32, ncclMax, cm->nccl, st));    /* 4 bytes, on the device word */
         return 0;
@@ -217,6 +229,22 @@ typedef struct xchg {      /* what the exchange of a step needs besides the comm
 /* the halo exchange of this step with sph_slab_step_overlap beside it; on return the receive buffers are (rccl: will be,
  * in stream order) filled and sph_slab_step_end may follow */
 static int comm_exchange(comm *cm, sph_ctx *ctx, const xchg *x) {
+    if (cm->selfcomm && cm->kind == TR_RCCL && cm->nranks == 1) {
+        /* what the enqueue and the RCCL kernels of a step cost without a neighbour to wait for: both halo buffers sent to
+         * this rank itself (the slab has no neighbours: it ignores what arrives) */
+        HIPCHK(hipEventRecord(x->packed, x->st));
+        HIPCHK(hipStreamWaitEvent(x->xst, x->packed, 0));
+        NCCLCHK(ncclGroupStart());
+        NCCLCHK(ncclSend(x->send_l, x->halo_bytes, ncclChar, 0, cm->nccl, x->xst));
+        NCCLCHK(ncclRecv(x->recv_l, x->halo_bytes, ncclChar, 0, cm->nccl, x->xst));
+        NCCLCHK(ncclSend(x->send_r, x->halo_bytes, ncclChar, 0, cm->nccl, x->xst));
+        NCCLCHK(ncclRecv(x->recv_r, x->halo_bytes, ncclChar, 0, cm->nccl, x->xst));
+        NCCLCHK(ncclGroupEnd());
+        HIPCHK(hipEventRecord(x->arrived, x->xst));
+        SPHCHK(ctx, sph_slab_step_overlap(ctx));
+        HIPCHK(hipStreamWaitEvent(x->st, x->arrived, 0));
+        return 0;
+    }
     if (!(x->has_left || x->has_right)) return 0;
     if (cm->kind == TR_RCCL) {
         /* the exchange on its own stream, behind the pack; the interior density pass runs beside it */
@@ -244,6 +272,23 @@ static int comm_exchange(comm *cm, sph_ctx *ctx, const xchg *x) {
     CHK(comm_barrier(cm));
     if (x->has_left) SPHCHK(ctx, sph_slab_copy_in(ctx, 0, shm_mail(cm, par, cm->rank - 1, 1)));       /* what the left neighbour sent right */
     if (x->has_right) SPHCHK(ctx, sph_slab_copy_in(ctx, 1, shm_mail(cm, par, cm->rank + 1, 0)));
+    return 0;
+}
+
+/* rccl: the exchange on the MAIN stream (the interior density pass runs on the side stream: step_once) */
+static int comm_exchange_inline(comm *cm, const xchg *x) {
+    const int self = cm->selfcomm && cm->nranks == 1;
+    if (!(x->has_left || x->has_right || self)) return 0;
+    NCCLCHK(ncclGroupStart());
+    if (x->has_left || self) {
+        NCCLCHK(ncclSend(x->send_l, x->halo_bytes, ncclChar, self ? 0 : cm->rank - 1, cm->nccl, x->st));
+        NCCLCHK(ncclRecv(x->recv_l, x->halo_bytes, ncclChar, self ? 0 : cm->rank - 1, cm->nccl, x->st));
+    }
+    if (x->has_right || self) {
+        NCCLCHK(ncclSend(x->send_r, x->halo_bytes, ncclChar, self ? 0 : cm->rank + 1, cm->nccl, x->st));
+        NCCLCHK(ncclRecv(x->recv_r, x->halo_bytes, ncclChar, self ? 0 : cm->rank + 1, cm->nccl, x->st));
+    }
+    NCCLCHK(ncclGroupEnd());
     return 0;
 }
 
@@ -474,6 +519,30 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
 /* one time step (:612-641) of this rank's slab */
 static int step_once(rank_state *rs, float gx, float gy) {
     SPHCHK(rs->ctx, sph_slab_step_begin(rs->ctx, gx, gy));
+    if (rs->cm.kind == TR_RCCL && (rs->cm.nranks > 1 || rs->cm.selfcomm) && rs->cm.serial == 2) {
+        /* everything on the main stream, nothing beside anything: no cross-stream event at all */
+        CHK(comm_reduce_word(&rs->cm, rs->ctx, rs->flag, rs->st));
+        SPHCHK(rs->ctx, sph_slab_step_pack(rs->ctx));
+        CHK(comm_exchange_inline(&rs->cm, &rs->x));
+        SPHCHK(rs->ctx, sph_slab_step_end(rs->ctx));
+        return 0;
+    }
+    if (rs->cm.kind == TR_RCCL && (rs->cm.nranks > 1 || rs->cm.selfcomm) && !rs->cm.serial) {
+        /* The interior density pass on the side stream from here on: beside the all-reduce of the word, the pack and the
+         * exchange, which all stay on the main stream (a cross-stream event in FRONT of the RCCL kernels and another behind
+         * them cost ~6 + ~15 us of queue latency per step, measured with --selfcomm; waiting for a pass that has long
+         * finished costs nothing).  On a step that turns out to rebuild the pass has worked for nothing: see sph.h. */
+        HIPCHK(hipEventRecord(rs->x.packed, rs->st));
+        HIPCHK(hipStreamWaitEvent(rs->xst, rs->x.packed, 0));
+        SPHCHK(rs->ctx, sph_slab_step_overlap_on(rs->ctx, rs->xst));
+        HIPCHK(hipEventRecord(rs->x.arrived, rs->xst));
+        CHK(comm_reduce_word(&rs->cm, rs->ctx, rs->flag, rs->st));
+        SPHCHK(rs->ctx, sph_slab_step_pack(rs->ctx));
+        CHK(comm_exchange_inline(&rs->cm, &rs->x));
+        HIPCHK(hipStreamWaitEvent(rs->st, rs->x.arrived, 0));
+        SPHCHK(rs->ctx, sph_slab_step_end(rs->ctx));
+        return 0;
+    }
     CHK(comm_reduce_word(&rs->cm, rs->ctx, rs->flag, rs->st));
     SPHCHK(rs->ctx, sph_slab_step_pack(rs->ctx));
     CHK(comm_exchange(&rs->cm, rs->ctx, &rs->x));
@@ -558,7 +627,7 @@ static int rebalance(rank_state *rs, float gx, float gy, double min_gain, int *m
 
 int main(int argc, char **argv) {
     int nranks = 1, rank = -1, steps = 200, warmup = 50, tilt = 0, check = 0, deterministic = 0, transport = TR_RCCL;
-    int rebalance_every = 0, capacity = 0, console = 0;
+    int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2;
     float skin = -1;
     const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL;
     scene_t sc = {0, 0, 0.3f, 0.3f, 0, 0, 0, 0, NULL};
@@ -582,6 +651,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--dump-state") && i + 1 < argc) state_file = argv[++i];
         else if (!strcmp(argv[i], "--tilt")) tilt = 1;
         else if (!strcmp(argv[i], "--console")) console = 1;
+        else if (!strcmp(argv[i], "--selfcomm")) selfcomm = 1;
+        else if (!strcmp(argv[i], "--exchange-stream") && i + 1 < argc) { i++; xside = !strcmp(argv[i], "side") ? 1 : !strcmp(argv[i], "main") ? 0 : 2; }
         else if (!strcmp(argv[i], "--deterministic")) deterministic = 1;
         else if (!strcmp(argv[i], "--skin") && i + 1 < argc) skin = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--check")) check = 1;
@@ -639,6 +710,8 @@ int main(int argc, char **argv) {
     rs.cm.kind = transport;
     rs.cm.rank = rank;
     rs.cm.nranks = nranks;
+    rs.cm.selfcomm = selfcomm;
+    rs.cm.serial = xside;
     rs.cm.coll_bytes = coll_bytes;
     rs.cm.halo_bytes = (halo_bytes + 63) / 64 * 64;
 

@@ -71,6 +71,23 @@ def test_c_host_one_rank_equals_sph_step(sph):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("order", ["serial", "main", "side"])
+def test_c_host_rccl_calls_of_a_step_against_itself(sph, order):
+    """--selfcomm: one rank issues the RCCL calls every step of an N > 1 run makes — the all-reduce on the device word, the
+    grouped send / receive of both halo buffers — to itself, in each of the three stream orders (--exchange-stream): the
+    streams, events and RCCL enqueues of the multi-GPU step on a one-GPU box.  What arrives is ignored (the slab has no
+    neighbours), so the run must still equal sph_step (--check)."""
+    r = subprocess.run([HOST, "--ranks", "1", "--block", "600", "150", "90", "20", "--steps", "150", "--warmup", "50", "--check",
+                        "--selfcomm", "--exchange-stream", order], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = r.stdout.decode().splitlines()
+    rec = json.loads([ln for ln in out if ln.startswith("{")][0])
+    assert rec["n_fluid"] == 90000 and rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200
+    chk = [ln for ln in out if ln.startswith("check:")]
+    assert len(chk) == 1 and chk[0].endswith("-> ok"), chk
+
+
+@pytest.mark.gpu
 def test_c_host_tilt_run_and_rank_count_guard(sph):
     r = subprocess.run([HOST, "--ranks", "1", "--scene", "dam", "--steps", "60", "--warmup", "20", "--tilt"],
                        capture_output=True, timeout=600)
