@@ -58,6 +58,12 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
+# launches per kernel of the duration measurement in front of the timed region (run_single): enough of them that a fresh
+# box has reached its running clocks when the window starts — the driver times 20 steps (2 ms) after 5, and a GPU that
+# has worked for 5 ms in its life runs the force pass in 64 us instead of 53
+PRE_REPS = int(os.environ.get("SPH_BENCH_PRE_REPS", "300"))
+
+
 def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False, windows=1, load_state=None, save_state=None):
     """`windows` timed windows of `steps` steps each of one scene on device 0, after `warmup` steps; returns a result dict
     (rates: the median window; windows = 1: exactly `steps` timed steps).  tilt: gravity from the scripted tilt trace
@@ -96,7 +102,7 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
         np.savez(save_state, particles=ctx.read_particles(), du=du_, dv=dv_)
     # the two heavy kernels at the START of the timed region (back-to-back launches of the idempotent kernels on the live
     # state); again at its end below: their mean is the figure for "the kernel's average duration over the timed region"
-    k_begin = (ctx.time_kernel("density_eos", 30), ctx.time_kernel("force_kick", 30)) if warmup > 0 and not load_state else None
+    k_begin = (ctx.time_kernel("density_eos", PRE_REPS), ctx.time_kernel("force_kick", PRE_REPS)) if warmup > 0 and not load_state else None
     rates, rebuilt = [], []
     for _ in range(windows):
         r0, _d = ctx.rebuild_stats()
