@@ -778,10 +778,19 @@ int main(int argc, char **argv) {
 
     /* ---- step loop ---- */
     double t0 = 0, last_reported = now_s();
+    float dens0_ms = 0, force0_ms = 0;
+    const int pre_reps = getenv("SPH_BENCH_PRE_REPS") ? atoi(getenv("SPH_BENCH_PRE_REPS")) : 300;
     float last_t = 0, worst_rho_err = 0, worst_speed = 0;
     int rebalanced = 0;
     for (int s = 0; s < warmup + steps; s++) {
         if (s == warmup) {
+            /* the two heavy kernels at the start of the timed region (back-to-back launches on the live state; again at
+             * the end: the JSON line reports their mean) — and enough of them that a fresh GPU has reached its running
+             * clocks when a short window (the driver's 20 steps) begins: bench.py does the same at N = 1 */
+            if (s > 0 && pre_reps > 0) {
+                SPHCHK(rs.ctx, sph_time_kernel(rs.ctx, SPH_K_DENSITY_EOS, pre_reps, &dens0_ms));
+                SPHCHK(rs.ctx, sph_time_kernel(rs.ctx, SPH_K_FORCE_KICK, pre_reps, &force0_ms));
+            }
             HIPCHK(hipStreamSynchronize(rs.st));
             HIPCHK(hipStreamSynchronize(rs.xst));
             CHK(comm_barrier(&rs.cm));
@@ -857,6 +866,7 @@ int main(int argc, char **argv) {
     if (steps + warmup > 0) {
         SPHCHK(rs.ctx, sph_time_kernel(rs.ctx, SPH_K_DENSITY_EOS, 20, &dens_ms));
         SPHCHK(rs.ctx, sph_time_kernel(rs.ctx, SPH_K_FORCE_KICK, 20, &force_ms));
+        if (dens0_ms > 0 && force0_ms > 0) { dens_ms = 0.5f * (dens_ms + dens0_ms); force_ms = 0.5f * (force_ms + force0_ms); }
     }
     if (rank == 0) {
         const double tps = steps > 0 ? (double)steps / elapsed : 0.0;
