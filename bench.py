@@ -389,7 +389,48 @@ def run_c_host(sph, args):
                      "step_unit": "GB/s per GPU (whole step, 152 B per particle-step)"},
         "cpu_baseline": cached_cpu_baseline(),      # measured by the N = 1 run on this host (None if there was none)
     }
+    if args.transport == "peer":
+        out["config"]["parallelism"] = ("%d x-slabs, one process per GPU, C host (slab_sph_fluid): per step the halo stored into the neighbours' "
+                                        "hipIpc-mapped memory and the rebuild words exchanged as flag stores (no collective library)" % world)
+    if args.transport == "rccl" and world > 1 and not args.no_also:
+        out["peer_transport"] = peer_leg(host, scene, world, args)
     emit(out)
+
+
+def peer_leg(host, scene, world, args):
+    """After the RCCL run (whose numbers are the line's `value`): the same workload once more with --transport peer — the
+    step's traffic as stores into hipIpc-mapped peer memory and flag words, three small kernels instead of RCCL's
+    all-reduce and send / receive — started by the C host's own launcher, in its own process group, under a time limit.
+    A one-GPU pool cannot exercise that transport between GPUs; this leg is how it gets its first run over xGMI without
+    putting the headline at risk.  Whatever happens here is reported, never raised."""
+    import signal
+    cmd = [host, "--scene", scene, "--steps", str(args.steps), "--warmup", str(args.warmup), "--transport", "peer", "--ranks", str(world)]
+    if args.workload == "cfg4":
+        cmd.append("--tilt")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    except OSError as e:
+        return {"status": "not started: %s" % e}
+    try:
+        so, se = p.communicate(timeout=float(os.environ.get("SPH_BENCH_PEER_TIMEOUT", "180")))
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)      # (the launcher and the ranks it started: this leg's own process group)
+        except OSError:
+            pass
+        p.communicate()
+        return {"status": "timed out"}
+    lines = [ln for ln in so.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"status": "failed (exit %d)" % p.returncode, "stderr_tail": se.decode(errors="replace")[-600:]}
+    d = json.loads(lines[-1])
+    return {"status": "ok", "value": round(d["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s", "timesteps_per_s": round(d["ticks_per_s"], 2),
+            "ms_per_step": d["ms_per_step"], "particles_conserved": d["particles_conserved"], "host": d["host"],
+            "kernel_ms": {"density_eos": d.get("rank0_density_ms"), "force_kick": d.get("rank0_force_ms")}}
 
 
 def main():
@@ -403,9 +444,10 @@ def main():
     ap.add_argument("--save-state", default=None, help="N = 1: write the state after the warm-up (particles + accelerations, .npz)")
     ap.add_argument("--load-state", default=None, help="N = 1: start from a state written by --save-state (then --warmup, then the timed steps)")
     ap.add_argument("--tilt", action="store_true", help="N = 1: gravity from the scripted tilt trace (cfg4 is defined with it)")
-    ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "rccl"), choices=["rccl", "host"],
+    ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "rccl"), choices=["rccl", "host", "peer"],
                     help="N > 1: halo transport. rccl = RCCL over xGMI, one GPU per rank; host = host-staged (C host: POSIX "
-                         "shared memory; python host: gloo): a rehearsal, all ranks may share one device")
+                         "shared memory; python host: gloo): a rehearsal, all ranks may share one device; peer = stores into "
+                         "hipIpc-mapped peer memory + flag words (C host), no collective library on the step path")
     ap.add_argument("--lib", default=None, help="A/B measurements: load this build of libsph_hip.so instead of the in-tree one")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin as a fraction of 2H (default: the library's)")
     ap.add_argument("--slab-host", default="c", choices=["c", "python"],

@@ -286,6 +286,25 @@ int  sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void 
 /* host-staged transport (tests, non-RCCL hosts): side 0 = left, 1 = right */
 int  sph_slab_copy_out(sph_ctx *ctx, int side, void *host_bytes);
 int  sph_slab_copy_in(sph_ctx *ctx, int side, const void *host_bytes);
+/* ---- peer-mapped transport (ranks of ONE node; xGMI is point to point and every GPU can map its peers' memory) ----
+ * Instead of a collective library on the per-step path: the HOST allocates, per rank, the two receive buffers
+ * (sph_slab_set_buffers), two arrival flags and a slot array uint32[2][SPH_PEER_MAX_RANKS], exports them (hipIpcGetMemHandle)
+ * and opens its peers'; per step, all on the context's stream, with `tag` = a number that grows by one per step:
+ *     sph_slab_step_begin
+ *     sph_slab_peer_reduce   stores this rank's rebuild word into its slot of every rank's array, waits for theirs: MAX
+ *     sph_slab_step_pack
+ *     sph_slab_peer_push     copies the send buffers into the neighbours' receive buffers, then raises their arrival flags
+ *     sph_slab_peer_wait     waits for this rank's two arrival flags
+ *     sph_slab_step_end
+ * One receive buffer per side is enough: a neighbour can only push step t + 1 after its own peer_reduce of step t + 1,
+ * which needs this rank's word of step t + 1, which this rank's stream stores after its sph_slab_step_end of step t.
+ * All waits are bounded: a peer that never arrives ends in SPH_E_STATE at the next call that reads the flags.
+ * slots_of_rank[q] = the address (in this process) of rank q's slot array, q = 0 .. n_ranks - 1 (entry `me`: its own);
+ * a missing neighbour: NULL buffer and flag. */
+#define SPH_PEER_MAX_RANKS 8
+int  sph_slab_peer_reduce(sph_ctx *ctx, void *const *slots_of_rank, int me, int n_ranks, uint32_t tag);
+int  sph_slab_peer_push(sph_ctx *ctx, void *left_recv_right, void *left_flag, void *right_recv_left, void *right_flag, uint32_t tag);
+int  sph_slab_peer_wait(sph_ctx *ctx, const void *flag_from_left, const void *flag_from_right, uint32_t tag);
 /* bytes of one halo buffer of a slab created with these parameters and this halo_capacity (0 = default): what a host
  * needs to know before it creates the context (shared-memory transports size their mailboxes with it) */
 size_t sph_slab_halo_bytes(const sph_params *prm, int halo_capacity);

@@ -1165,6 +1165,35 @@ int sph_slab_copy_in(sph_ctx *ctx, int side, const void *host) {
     return SPH_OK;
 }
 
+int sph_slab_peer_reduce(sph_ctx *ctx, void *const *slots_of_rank, int me, int n_ranks, uint32_t tag) {
+    if (!ctx || !ctx->stream || !ctx->slab || !slots_of_rank || n_ranks < 1 || n_ranks > SPH_PEER_MAX_RANKS || me < 0 || me >= n_ranks)
+        return SPH_E_ARG;
+    if (ctx->slab_phase != 1) return fail(ctx, SPH_E_STATE, "sph_slab_peer_reduce: between sph_slab_step_begin and sph_slab_step_pack");
+    for (int q = 0; q < n_ranks; q++)
+        if (!slots_of_rank[q]) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_peer_reduce(ctx->stream, ctx->a, slots_of_rank, slots_of_rank[me], me, n_ranks, tag);
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_slab_peer_push(sph_ctx *ctx, void *left_recv_right, void *left_flag, void *right_recv_left, void *right_flag, uint32_t tag) {
+    if (!ctx || !ctx->stream || !ctx->slab || (!left_recv_right) != (!left_flag) || (!right_recv_left) != (!right_flag)) return SPH_E_ARG;
+    if (ctx->slab_phase != 2) return fail(ctx, SPH_E_STATE, "sph_slab_peer_push without sph_slab_step_pack");
+    (void)hipSetDevice(ctx->device);
+    launch_peer_push(ctx->stream, ctx->c, ctx->a, left_recv_right, left_flag, right_recv_left, right_flag, tag);
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_slab_peer_wait(sph_ctx *ctx, const void *flag_from_left, const void *flag_from_right, uint32_t tag) {
+    if (!ctx || !ctx->stream || !ctx->slab) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    launch_peer_wait(ctx->stream, ctx->a, flag_from_left, flag_from_right, tag);
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
 int sph_slab_read(sph_ctx *ctx, sph_particle *out, uint32_t *ids, float *du_dt, float *dv_dt, int cap, int *n_out) {
     if (!ctx || !ctx->stream || !ctx->slab || !n_out) return SPH_E_ARG;
     if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_read mid-step");

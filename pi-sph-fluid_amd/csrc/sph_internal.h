@@ -124,7 +124,8 @@ enum {
     FLAG_OFF_XCD = 19,      // workgroups of one-launch rebuilds so far that did not run on the XCD of their barrier leader
     FLAG_STEP = 20,         // steps so far (k_check counts them)
     FLAG_LAST_REBUILD = 21, // FLAG_STEP at the last rebuild
-    FLAG_COUNT = 22
+    FLAG_PEER_DONE = 22,    // workgroups of k_peer_push that have finished (grows: the last one of a launch raises the flags)
+    FLAG_COUNT = 23
 };
 // Arrays::dyn
 enum {
@@ -179,6 +180,9 @@ int rebuild_grid(int device, int cap);
 void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool selftest = false, bool deterministic = false);
 // slab mode, what follows the halo exchange, as one launch: ghost update, or (rebuild step) ingest -> scan -> scatter ->
 // canonical order of the interface cells -> tile records + lists
+void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag);
+void launch_peer_push(hipStream_t st, const Consts &c, const Arrays &a, void *remote_l, void *flag_l, void *remote_r, void *flag_r, uint32_t tag);
+void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const void *flag_r, uint32_t tag);
 void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool deterministic = false);
 // raise the rebuild request: the next step rebuilds the neighbour structure
 void launch_request_rebuild(hipStream_t st, const Arrays &a);

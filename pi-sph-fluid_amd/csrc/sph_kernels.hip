@@ -989,6 +989,92 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
     if (KICK) velt[i] = make_float2(fmaf(c.half_dt, ax, vi.x), fmaf(c.half_dt, ay, vi.y));   // :638-639
 }
 
+// ------------------------------------------------------------------------------------------
+// Peer transport of the slab step (include/sph.h, "peer-mapped transport"): the ranks of one node map each other's receive
+// buffers and flag words (hipIpc handles, opened by the HOST) and the per-step traffic is plain stores over xGMI plus
+// flag words — three small kernels on the context's stream instead of an all-reduce and a send / receive of a collective
+// library.  Everything that crosses between ranks is written with system-scope release stores behind a system-scope
+// fence (the data has left this device's caches) and read with system-scope acquire loads in a kernel of its own (the
+// kernels that follow start with freshly invalidated caches).  All waits are bounded (FLAG_BAR_TIMEOUT -> SPH_E_STATE).
+constexpr uint32_t PEER_SPINS = 1u << 23;      // x ~0.2 us per poll: a few seconds
+DEV bool peer_wait(const uint32_t *__restrict__ word, const uint32_t tag, const uint32_t shift, uint32_t *__restrict__ flags, uint32_t &value) {
+    uint32_t spins = 0u;
+    for (;;) {
+        value = __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((value >> shift) == tag) return true;
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > PEER_SPINS) {
+            atomicOr(&flags[FLAG_BAR_TIMEOUT], 1u);
+            return false;
+        }
+    }
+}
+struct PeerSlots { uint32_t *of_rank[SPH_PEER_MAX_RANKS]; };
+// MAX over the ranks of the rebuild word.  Every rank owns slots[2][SPH_PEER_MAX_RANKS] (parity of the step x sender):
+// thread q stores (tag << 1 | my word) into MY slot of rank q's array, then waits for rank q's entry in this rank's array.
+__global__ __launch_bounds__(64) void k_peer_reduce(PeerSlots peers, const uint32_t *__restrict__ mine, uint32_t *__restrict__ rebuild,
+                                                    uint32_t *__restrict__ flags, int me, int nranks, uint32_t tag) {
+    const int q = (int)threadIdx.x;
+    const uint32_t par = (tag & 1u) * (uint32_t)SPH_PEER_MAX_RANKS;
+    const uint32_t w = *rebuild;
+    uint32_t got = w;
+    if (q < nranks && q != me) {
+        __hip_atomic_store(peers.of_rank[q] + par + (uint32_t)me, (tag << 2) | (w & 3u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t v = 0u;
+        if (peer_wait(mine + par + (uint32_t)q, tag, 2u, flags, v)) got = v & 3u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) got = max(got, (uint32_t)__shfl_xor((int)got, d, 64));
+    if (q == 0) *rebuild = got;
+}
+// The two send buffers of this step into the neighbours' receive buffers (as many bytes as the header says), then —
+// by the last workgroup to finish, behind a system-scope fence in every workgroup — the neighbours' arrival flags.
+__global__ __launch_bounds__(BLK) void k_peer_push(const uint32_t *__restrict__ send_l, const uint32_t *__restrict__ send_r,
+                                                   uint32_t *__restrict__ remote_l, uint32_t *__restrict__ remote_r,
+                                                   uint32_t *__restrict__ flag_l, uint32_t *__restrict__ flag_r,
+                                                   uint32_t *__restrict__ done, int halo_cap, uint32_t tag) {
+    for (int side = 0; side < 2; side++) {
+        const uint32_t *src = side == 0 ? send_l : send_r;
+        uint32_t *dst = side == 0 ? remote_l : remote_r;
+        if (!dst) continue;
+        const uint32_t count = min(src[0], (uint32_t)halo_cap), kind = src[1];
+        const uint32_t words = (uint32_t)HALO_HDR + count * (kind == 0u ? (uint32_t)HALO_REC : 4u), quads = (words + 3u) / 4u;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (uint32_t k = blockIdx.x * BLK + threadIdx.x; k < quads; k += gridDim.x * BLK) d4[k] = s4[k];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t arrived = atomicAdd(done, 1u);      // (grows by gridDim.x per launch: never reset)
+        if ((arrived + 1u) % gridDim.x == 0u) {
+            __threadfence_system();
+            if (flag_l) __hip_atomic_store(flag_l, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (flag_r) __hip_atomic_store(flag_r, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_peer_wait(const uint32_t *__restrict__ flag_l, const uint32_t *__restrict__ flag_r,
+                                                  uint32_t *__restrict__ flags, uint32_t tag) {
+    uint32_t v;
+    if (threadIdx.x == 0 && flag_l) (void)peer_wait(flag_l, tag, 0u, flags, v);
+    if (threadIdx.x == 1 && flag_r) (void)peer_wait(flag_r, tag, 0u, flags, v);
+}
+void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag) {
+    PeerSlots ps;
+    for (int q = 0; q < SPH_PEER_MAX_RANKS; q++) ps.of_rank[q] = q < nranks ? static_cast<uint32_t *>(slots_of_rank[q]) : nullptr;
+    hipLaunchKernelGGL(k_peer_reduce, dim3(1), dim3(64), 0, st, ps, static_cast<const uint32_t *>(mine), a.rebuild, a.flags, me, nranks, tag);
+}
+void launch_peer_push(hipStream_t st, const Consts &c, const Arrays &a, void *remote_l, void *flag_l, void *remote_r, void *flag_r, uint32_t tag) {
+    constexpr int PUSH_WGS = 32;
+    hipLaunchKernelGGL(k_peer_push, dim3(PUSH_WGS), dim3(BLK), 0, st, a.send[0], a.send[1], static_cast<uint32_t *>(remote_l),
+                       static_cast<uint32_t *>(remote_r), static_cast<uint32_t *>(flag_l), static_cast<uint32_t *>(flag_r),
+                       a.flags + FLAG_PEER_DONE, c.halo_cap, tag);
+}
+void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const void *flag_r, uint32_t tag) {
+    hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, st, static_cast<const uint32_t *>(flag_l), static_cast<const uint32_t *>(flag_r), a.flags, tag);
+}
+
 }  // namespace sph
 
 #include "sph_list.inc"

@@ -19,9 +19,14 @@
  *   host  the same protocol with POSIX shared memory between the ranks: the word through sph_slab_flag_get / _set, the
  *         buffers through sph_slab_copy_out / _copy_in, a process-shared barrier between writing and reading.  Ranks may
  *         share a device: rehearsals and tests of THIS file's step loop, re-balancing and statistics on a one-GPU box.
- * The two differ only in the functions under "transport" below; the step loop is one.
+ *   peer  the per-step traffic as plain stores into the neighbours' memory, mapped through hipIpc handles (xGMI is point to
+ *         point), and flag words: sph_slab_peer_reduce / _push / _wait (include/sph.h), three small kernels per step on the
+ *         one stream instead of an all-reduce and a send / receive kernel.  Set-up and the small collectives (statistics,
+ *         re-balancing) go through the shared-memory segment of `host`.  Ranks may share a device (tests); on a node with
+ *         one GPU per rank this is the transport without a collective library on the step path.  Up to 8 ranks.
+ * The three differ only in the functions under "transport" below; the step loop is one.
  *
- *   slab_sph_fluid --ranks N [--transport rccl|host] [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--origin X0 Y0]
+ *   slab_sph_fluid --ranks N [--transport rccl|host|peer] [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--origin X0 Y0]
  *                  [--velocity U V] [--steps K] [--warmup W] [--tilt] [--check] [--deterministic] [--skin F]
  *                  [--rebalance-every K] [--capacity N] [--console] [--frame FILE] [--dump-state FILE] [--selfcomm]
  *                  [--exchange-stream serial|main|side]
@@ -87,7 +92,7 @@ typedef struct {
 /* ------------------------------------------------------------------------------------------------------------------
  * transport: what the step loop needs from the ranks' interconnect
  * ---------------------------------------------------------------------------------------------------------------- */
-enum { TR_RCCL = 0, TR_HOST = 1 };
+enum { TR_RCCL = 0, TR_HOST = 1, TR_PEER = 2 };      /* (host and peer: set-up and the small collectives through shared memory) */
 
 typedef struct shm_hdr {
     pthread_barrier_t bar;
@@ -164,7 +169,7 @@ static int shm_attach(comm *cm, const char *name) {
 
 static int comm_barrier(comm *cm) {
     if (cm->nranks == 1) return 0;
-    if (cm->kind == TR_HOST) {
+    if (cm->kind != TR_RCCL) {
         const int rc = pthread_barrier_wait(&cm->shm->bar);
         return rc != 0 && rc != PTHREAD_BARRIER_SERIAL_THREAD;
     }
@@ -488,7 +493,80 @@ typedef struct rank_state {
     int c0, c1;                  /* owned columns */
     void *flag;
     xchg x;
+    /* peer transport: this rank's block (send / receive buffers, arrival flags, word slots) and its peers' blocks as
+     * mapped into this process */
+    void *peer_blk, *peer_of[SPH_PEER_MAX_RANKS];
+    size_t peer_halo;            /* bytes per halo buffer inside a block */
+    uint32_t peer_tag;
 } rank_state;
+
+/* layout of a peer block: [send_l][send_r][recv_l][recv_r][flag from left | flag from right (256 B apart)][slots] */
+static size_t peer_off_recv(const rank_state *rs, int side) { return (size_t)(2 + side) * rs->peer_halo; }
+static size_t peer_off_flag(const rank_state *rs, int side) { return 4 * rs->peer_halo + (size_t)side * 256; }
+static size_t peer_off_slots(const rank_state *rs) { return 4 * rs->peer_halo + 512; }
+static size_t peer_block_bytes(const rank_state *rs) { return peer_off_slots(rs) + sizeof(uint32_t) * 2 * SPH_PEER_MAX_RANKS + 256; }
+
+/* allocate and export this rank's block, open the others' (collective; once per run: the block outlives re-balancing) */
+static int peer_setup(rank_state *rs, size_t halo_bytes) {
+    comm *cm = &rs->cm;
+    if (cm->nranks > SPH_PEER_MAX_RANKS) { fprintf(stderr, "[rank %d] the peer transport serves up to %d ranks\n", cm->rank, SPH_PEER_MAX_RANKS); return 1; }
+    rs->peer_halo = (halo_bytes + 255) / 256 * 256;
+    const size_t bytes = peer_block_bytes(rs);
+    /* fine-grained device memory where the runtime exports it (what a peer writes must not linger in anybody's cache);
+     * SPH_PEER_COARSE=1: plain hipMalloc (the kernels fence at system scope either way) */
+    hipError_t e = hipErrorUnknown;
+    int e_fine = 0;
+    if (!getenv("SPH_PEER_COARSE")) e = hipExtMallocWithFlags(&rs->peer_blk, bytes, hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e_fine = 1;
+    else { (void)hipGetLastError(); HIPCHK(hipMalloc(&rs->peer_blk, bytes)); }
+    HIPCHK(hipMemset(rs->peer_blk, 0, bytes));
+    HIPCHK(hipDeviceSynchronize());
+    long long hs[SPH_PEER_MAX_RANKS * 8 + SPH_PEER_MAX_RANKS];      /* 64-byte handles, then the ranks' devices */
+    memset(hs, 0, sizeof hs);
+    if (cm->nranks > 1) {
+        hipIpcMemHandle_t h;
+        e = hipIpcGetMemHandle(&h, rs->peer_blk);
+        if (e != hipSuccess && !getenv("SPH_PEER_COARSE")) {      /* (a runtime that does not export fine-grained memory) */
+            (void)hipGetLastError();
+            (void)hipFree(rs->peer_blk);
+            e_fine = 0;
+            HIPCHK(hipMalloc(&rs->peer_blk, bytes));
+            HIPCHK(hipMemset(rs->peer_blk, 0, bytes));
+            HIPCHK(hipDeviceSynchronize());
+            e = hipIpcGetMemHandle(&h, rs->peer_blk);
+        }
+        if (e != hipSuccess) { fprintf(stderr, "[rank %d] hipIpcGetMemHandle: %s\n", cm->rank, hipGetErrorString(e)); return 1; }
+        _Static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+        memcpy(&hs[cm->rank * 8], &h, 64);
+        hs[SPH_PEER_MAX_RANKS * 8 + cm->rank] = rs->device;
+        CHK(comm_allreduce(cm, hs, SPH_PEER_MAX_RANKS * 8 + SPH_PEER_MAX_RANKS, 0));      /* (sum with zeros: an all-gather) */
+    }
+    for (int q = 0; q < cm->nranks; q++) {
+        if (q == cm->rank) { rs->peer_of[q] = rs->peer_blk; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, &hs[q * 8], 64);
+        const int qdev = (int)hs[SPH_PEER_MAX_RANKS * 8 + q];
+        if (qdev != rs->device) {      /* (another GPU of the node: its memory over xGMI) */
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, rs->device, qdev);
+            if (!can) { fprintf(stderr, "[rank %d] device %d cannot map device %d\n", cm->rank, rs->device, qdev); return 1; }
+            e = hipDeviceEnablePeerAccess(qdev, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { fprintf(stderr, "[rank %d] hipDeviceEnablePeerAccess(%d): %s\n", cm->rank, qdev, hipGetErrorString(e)); return 1; }
+            (void)hipGetLastError();
+        }
+        e = hipIpcOpenMemHandle(&rs->peer_of[q], h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { fprintf(stderr, "[rank %d] hipIpcOpenMemHandle(rank %d): %s\n", cm->rank, q, hipGetErrorString(e)); return 1; }
+    }
+    CHK(comm_barrier(cm));
+    fprintf(stderr, "[rank %d] peer block of %zu bytes (%s), %d peer block(s) mapped\n", cm->rank, bytes,
+            e_fine ? "fine-grained" : "coarse-grained: system-scope fences only", cm->nranks - 1);
+    return 0;
+}
+static void peer_teardown(rank_state *rs) {
+    for (int q = 0; q < rs->cm.nranks; q++)
+        if (q != rs->cm.rank && rs->peer_of[q]) (void)hipIpcCloseMemHandle(rs->peer_of[q]);
+    if (rs->peer_blk) (void)hipFree(rs->peer_blk);
+}
 
 /* a slab context for columns [c0, c1) from the particles given, wired to the rank's streams and transport */
 static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc, const unsigned *ids, long n_loc, float gx, float gy) {
@@ -499,8 +577,13 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
     /* one rank per GPU (rccl): nothing else computes on this device, so what follows the halo exchange may run as one
      * launch with grid barriers (include/sph.h, sph_set_rebuild_launches); ranks that may share a device must not */
     if (rs->transport == TR_RCCL) SPHCHK(rs->ctx, sph_set_rebuild_launches(rs->ctx, 1));
+    if (rs->transport == TR_PEER) {      /* the context sends from and receives into this rank's block */
+        char *b = (char *)rs->peer_blk;
+        SPHCHK(rs->ctx, sph_slab_set_buffers(rs->ctx, b, b + rs->peer_halo, b + peer_off_recv(rs, 0), b + peer_off_recv(rs, 1), rs->peer_halo));
+    }
     SPHCHK(rs->ctx, sph_slab_flag_buffer(rs->ctx, &rs->flag));
     SPHCHK(rs->ctx, sph_slab_buffers(rs->ctx, &rs->x.send_l, &rs->x.send_r, &rs->x.recv_l, &rs->x.recv_r, &rs->x.halo_bytes));
+    if (rs->transport == TR_PEER && rs->x.halo_bytes > rs->peer_halo) { fprintf(stderr, "[rank %d] halo buffers outgrew the peer block\n", rs->cm.rank); return 1; }
     if (rs->transport == TR_HOST && rs->cm.nranks > 1 && rs->x.halo_bytes > rs->cm.halo_bytes) {
         fprintf(stderr, "[rank %d] halo buffers of %zu bytes exceed the shared mailboxes (%zu)\n", rs->cm.rank, rs->x.halo_bytes, rs->cm.halo_bytes);
         return 1;
@@ -519,6 +602,30 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
 /* one time step (:612-641) of this rank's slab */
 static int step_once(rank_state *rs, float gx, float gy) {
     SPHCHK(rs->ctx, sph_slab_step_begin(rs->ctx, gx, gy));
+    if (rs->cm.kind == TR_PEER) {
+        /* everything between the ranks as stores into mapped peer memory and flag words, on the one stream */
+        const int me = rs->cm.rank, n = rs->cm.nranks;
+        const uint32_t tag = ++rs->peer_tag;
+        void *slots[SPH_PEER_MAX_RANKS];
+        for (int q = 0; q < n; q++) slots[q] = (char *)rs->peer_of[q] + peer_off_slots(rs);
+        if (n > 1 || rs->cm.selfcomm) SPHCHK(rs->ctx, sph_slab_peer_reduce(rs->ctx, slots, me, n, tag));
+        SPHCHK(rs->ctx, sph_slab_step_pack(rs->ctx));
+        if (rs->cm.selfcomm && n == 1) {      /* (a measurement: the three kernels of the step against this rank's own block) */
+            char *M = (char *)rs->peer_blk;
+            SPHCHK(rs->ctx, sph_slab_peer_push(rs->ctx, M + peer_off_recv(rs, 1), M + peer_off_flag(rs, 1), M + peer_off_recv(rs, 0), M + peer_off_flag(rs, 0), tag));
+            SPHCHK(rs->ctx, sph_slab_peer_wait(rs->ctx, M + peer_off_flag(rs, 0), M + peer_off_flag(rs, 1), tag));
+        } else if (rs->x.has_left || rs->x.has_right) {
+            char *L = rs->x.has_left ? (char *)rs->peer_of[me - 1] : NULL, *R = rs->x.has_right ? (char *)rs->peer_of[me + 1] : NULL;
+            /* my left neighbour receives me on ITS right side, and the other way round */
+            SPHCHK(rs->ctx, sph_slab_peer_push(rs->ctx, L ? L + peer_off_recv(rs, 1) : NULL, L ? L + peer_off_flag(rs, 1) : NULL,
+                                               R ? R + peer_off_recv(rs, 0) : NULL, R ? R + peer_off_flag(rs, 0) : NULL, tag));
+            char *M = (char *)rs->peer_blk;
+            SPHCHK(rs->ctx, sph_slab_peer_wait(rs->ctx, rs->x.has_left ? M + peer_off_flag(rs, 0) : NULL,
+                                               rs->x.has_right ? M + peer_off_flag(rs, 1) : NULL, tag));
+        }
+        SPHCHK(rs->ctx, sph_slab_step_end(rs->ctx));
+        return 0;
+    }
     if (rs->cm.kind == TR_RCCL && (rs->cm.nranks > 1 || rs->cm.selfcomm) && rs->cm.serial == 2) {
         /* everything on the main stream, nothing beside anything: no cross-stream event at all */
         CHK(comm_reduce_word(&rs->cm, rs->ctx, rs->flag, rs->st));
@@ -640,6 +747,7 @@ int main(int argc, char **argv) {
             const char *t = argv[++i];
             if (!strcmp(t, "rccl")) transport = TR_RCCL;
             else if (!strcmp(t, "host")) transport = TR_HOST;
+            else if (!strcmp(t, "peer")) transport = TR_PEER;
             else { fprintf(stderr, "unknown transport %s (rccl | host)\n", t); return 2; }
         }
         else if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene_name = argv[++i];
@@ -689,11 +797,11 @@ int main(int argc, char **argv) {
         snprintf(idbuf, sizeof idbuf, "/tmp/slab_sph_fluid.%d.%ld.id", (int)getpid(), (long)time(NULL));
         snprintf(shmbuf, sizeof shmbuf, "/slab_sph_fluid.%d.%ld", (int)getpid(), (long)time(NULL));
         unlink(idbuf);
-        if (transport == TR_HOST && nranks > 1 && shm_create(shmbuf, nranks, halo_bytes, coll_bytes)) return 1;
+        if (transport != TR_RCCL && nranks > 1 && shm_create(shmbuf, nranks, halo_bytes, coll_bytes)) return 1;
         if (nranks > 1) {
-            const int rc = launch(nranks, argc, argv, idbuf, transport == TR_HOST ? shmbuf : NULL);
+            const int rc = launch(nranks, argc, argv, idbuf, transport != TR_RCCL ? shmbuf : NULL);
             unlink(idbuf);
-            if (transport == TR_HOST) shm_unlink(shmbuf);
+            if (transport != TR_RCCL) shm_unlink(shmbuf);
             return rc;
         }
         rank = 0;                      /* one rank: in this process (no fork, no exec) */
@@ -764,12 +872,13 @@ int main(int argc, char **argv) {
         if (!shm_name) { fprintf(stderr, "[rank %d] --transport host needs --shm (the launcher passes it)\n", rank); return 1; }
         CHK(shm_attach(&rs.cm, shm_name));
     }
+    if (transport == TR_PEER) CHK(peer_setup(&rs, halo_bytes));
     const double t_create = now_s();
     CHK(make_context(&rs, c0, c1, loc, ids, n_loc, gx, gy));
     int n_local = 0, n_owned = 0;
     SPHCHK(rs.ctx, sph_slab_counts(rs.ctx, &n_local, &n_owned));
     fprintf(stderr, "[rank %d] columns [%d,%d) of %d, lattice columns [%ld,%ld), local/owned %d/%d, created in %.2f s, halo buffers %zu B, device %d, %s transport\n",
-            rank, c0, c1, cols, ib, ie, n_local, n_owned, now_s() - t_create, rs.x.halo_bytes, rs.device, transport == TR_RCCL ? "rccl" : "host");
+            rank, c0, c1, cols, ib, ie, n_local, n_owned, now_s() - t_create, rs.x.halo_bytes, rs.device, transport == TR_RCCL ? "rccl" : transport == TR_PEER ? "peer" : "host");
     if (console && rank == 0) {
         printf("dt = %f    (expected ticks/s) %d\n", prm.dt, (int)(1 / prm.dt));      /* :543 */
         printf("n_fluid = %ld\n", n_total);                                            /* :544 */
@@ -874,7 +983,7 @@ int main(int argc, char **argv) {
                "\"steps\": %d, \"warmup\": %d, \"ticks_per_s\": %.2f, \"mparticle_steps_per_s\": %.2f, \"ms_per_step\": %.5f, "
                "\"neighbour_rebuilds\": %lld, \"rebalanced\": %d, \"max_owned\": %lld, \"max_rho\": %.3f, \"max_speed\": %.3f, "
                "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s}\n",
-               transport == TR_RCCL ? "RCCL" : "host-staged shared memory", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
+               transport == TR_RCCL ? "RCCL" : transport == TR_PEER ? "peer-mapped memory" : "host-staged shared memory", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
                steps, warmup, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
                n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false");
         fflush(stdout);
@@ -934,6 +1043,7 @@ int main(int argc, char **argv) {
         if (!(dx <= tol)) return 1;
     }
     if (transport == TR_RCCL) { ncclCommDestroy(rs.cm.nccl); (void)hipFree(rs.cm.d_coll); }
+    if (transport == TR_PEER) peer_teardown(&rs);
     sph_destroy(rs.ctx);
     free(loc); free(ids); free(rs.walls); free(cuts);
     return 0;

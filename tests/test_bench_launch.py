@@ -95,3 +95,25 @@ def test_c_host_two_ranks_share_the_gpu_through_bench(sph):
     assert out["roofline"]["kernel"].startswith("force_kick") and 0 < out["roofline"]["frac"] < 1
     assert out["kernel_ms"]["force_kick"] > 0 and out["kernel_ms"]["density_eos"] > 0
     assert "cpu_baseline" in out
+
+
+@pytest.mark.gpu
+def test_c_host_two_ranks_over_peer_mapped_memory_through_bench(sph):
+    """bench.py --gpus 2 --transport peer: two processes on the one GPU of this box that store their halo buffers into each
+    other's hipIpc-mapped memory; and bench.peer_leg(), the guarded second run that an N > 1 RCCL bench adds to its line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "peer", "--steps", "30",
+                        "--warmup", "10"], capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["particles_conserved"] is True and out["config"]["n_fluid"] == 4000000
+    assert "hipIpc-mapped" in out["config"]["parallelism"] and "peer_transport" not in out
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    leg = bench.peer_leg(os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid"), "dam", 2,
+                         argparse.Namespace(steps=30, warmup=10, workload="cfg2"))
+    assert leg["status"] == "ok" and leg["particles_conserved"] is True and leg["timesteps_per_s"] > 0 and "peer-mapped" in leg["host"], leg
+    # a run that cannot start is reported, not raised
+    bad = bench.peer_leg(os.path.join(ROOT, "no_such_program"), "dam", 2, argparse.Namespace(steps=1, warmup=0, workload="cfg2"))
+    assert bad["status"].startswith("not started")

@@ -158,6 +158,40 @@ def _flying_block(sph, u=5.0, deterministic=True, skin=0.0):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [2, 4])
+def test_c_host_ranks_over_peer_mapped_memory_equal_sph_step_bitwise(sph, tmp_path, ranks):
+    """--transport peer on one GPU: the ranks (processes) map each other's receive buffers and flag words through hipIpc
+    handles; per step sph_slab_peer_reduce (the rebuild word: MAX over the ranks through slot stores), sph_slab_peer_push (the
+    halo buffers stored into the neighbours' memory, arrival flags) and sph_slab_peer_wait, all on the one stream.  Same
+    scene and same bar as the shared-memory transport below: bit for bit sph_step's particles after 300 steps."""
+    state = tmp_path / "state.bin"
+    r, out, rec = _run_host(["--ranks", ranks, "--transport", "peer", "--block", 600, 150, 90, 20, "--velocity", 5, 0, "--steps", 250,
+                             "--warmup", 50, "--deterministic", "--skin", 0, "--dump-state", state])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["n_gpus"] == ranks and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True and rec["neighbour_rebuilds"] >= 300
+    assert "peer-mapped" in rec["host"]
+    got = np.fromfile(state, sph.PARTICLE)
+    prm, f, b = _flying_block(sph)
+    with sph.Context(prm, f, b, 0.0, -9.81) as ctx:
+        ctx.step(300, 0.0, -9.81)
+        ctx.sync()
+        ref = ctx.read_particles()
+    assert len(got) == len(ref)
+    for k in ("x", "y", "u", "v", "rho", "p"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.gpu
+def test_c_host_peer_transport_default_skin_and_rebalancing(sph, tmp_path):
+    """the peer transport with the default (adaptive) skin — most steps carry updates, the ranks must agree on the steps
+    that rebuild — and re-balancing (contexts re-created, the peer blocks kept): particles conserved, the run ends cleanly"""
+    r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--block", 600, 150, 90, 20, "--velocity", 5, 0, "--steps", 500,
+                             "--warmup", 100, "--rebalance-every", 200])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 600
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 4])
 def test_c_host_ranks_over_shared_memory_equal_sph_step_bitwise(sph, tmp_path, ranks):
     """THE STEP LOOP OF THE C HOST WITH NEIGHBOURS, on one GPU: 2 and 4 ranks (processes) exchange the halo buffers and
     reduce the rebuild word through POSIX shared memory (--transport host: sph_slab_copy_out / _copy_in, sph_slab_flag_get /
