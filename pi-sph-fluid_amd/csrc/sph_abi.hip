@@ -54,8 +54,8 @@ struct sph_ctx {
     bool velt_stale = false;     // the fused force pass does not store the velocity between steps: refresh_velt() before use
     bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
-    hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};          // [0,1]: one step; [2,3]: MULTI_STEPS steps
-    hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraph_t graph[8] = {};          // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations)
+    hipGraphExec_t gexec[8] = {};
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
     bool one_launch_asked = false;  // sph_set_rebuild_launches(ctx, 1): the host vouches that nothing else computes on the device meanwhile
@@ -200,7 +200,7 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
 }
 
 void drop_graph(sph_ctx *ctx) {
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 8; k++) {
         if (ctx->gexec[k]) { (void)hipGraphExecDestroy(ctx->gexec[k]); ctx->gexec[k] = nullptr; }
         if (ctx->graph[k]) { (void)hipGraphDestroy(ctx->graph[k]); ctx->graph[k] = nullptr; }
     }
@@ -232,17 +232,17 @@ hipGraphExec_t step_graph(sph_ctx *ctx) {
 // MULTI_STEPS consecutive steps of the fused (primed) loop as ONE graph: a replay has a fixed cost of several
 // microseconds whatever it holds, and sph_step(nsteps) usually asks for many steps.  An even number of steps leaves the
 // orientation of the two position / velocity sets as it was.
-constexpr int MULTI_STEPS = 8;
-hipGraphExec_t multi_graph(sph_ctx *ctx) {
-    if (!ctx->use_graph) return nullptr;
-    const int k = 2 + (ctx->a.pos == ctx->pos_a ? 0 : 1);
+constexpr int MULTI_STEPS = 8;      // the largest; 4 and 2 serve the remainder of a call (20 steps = 8 + 8 + 4: three replays)
+hipGraphExec_t multi_graph(sph_ctx *ctx, int steps = MULTI_STEPS) {
+    if (!ctx->use_graph || (steps != 8 && steps != 4 && steps != 2)) return nullptr;
+    const int k = (steps == 8 ? 6 : steps == 4 ? 4 : 2) + (ctx->a.pos == ctx->pos_a ? 0 : 1);
     if (ctx->gexec[k]) return ctx->gexec[k];
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         ctx->use_graph = false;
         return nullptr;
     }
-    for (int s = 0; s < MULTI_STEPS; s++) {
+    for (int s = 0; s < steps; s++) {
         std::swap(ctx->a.pos, ctx->a.pos2);
         std::swap(ctx->a.vel, ctx->a.vel2);
         enqueue_step_body(ctx, nullptr);
@@ -266,8 +266,10 @@ void prebuild_graphs(sph_ctx *ctx) {
     for (int o = 0; o < 2 && ctx->use_graph; o++) {
         hipGraphExec_t g = step_graph(ctx);
         if (g) (void)hipGraphUpload(g, ctx->stream);
-        g = multi_graph(ctx);
-        if (g) (void)hipGraphUpload(g, ctx->stream);
+        for (int m = MULTI_STEPS; m >= 2; m >>= 1) {
+            g = multi_graph(ctx, m);
+            if (g) (void)hipGraphUpload(g, ctx->stream);
+        }
         std::swap(ctx->a.pos, ctx->a.pos2);
         std::swap(ctx->a.vel, ctx->a.vel2);
     }
@@ -627,13 +629,14 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     int s = 0;
     while (s < nsteps) {
-        if (fused(ctx) && ctx->primed && nsteps - s >= MULTI_STEPS) {
-            hipGraphExec_t g = multi_graph(ctx);
+        if (fused(ctx) && ctx->primed && nsteps - s >= 2) {
+            const int m = nsteps - s >= 8 ? 8 : nsteps - s >= 4 ? 4 : 2;
+            hipGraphExec_t g = multi_graph(ctx, m);
             if (g) {
                 HIPCHK(ctx, hipGraphLaunch(g, ctx->stream));
                 ctx->velt_stale = true;
                 ctx->p_stale = true;
-                s += MULTI_STEPS;
+                s += m;
                 continue;
             }
         }
