@@ -114,6 +114,14 @@ def test_c_host_two_ranks_over_peer_mapped_memory_through_bench(sph):
     leg = bench.peer_leg(os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid"), "dam", 2,
                          argparse.Namespace(steps=30, warmup=10, workload="cfg2"))
     assert leg["status"] == "ok" and leg["particles_conserved"] is True and leg["timesteps_per_s"] > 0 and "peer-mapped" in leg["host"], leg
+    # the default transport with more ranks than GPUs: the RCCL run refuses (one rank per GPU), bench.py falls back to the peer
+    # transport and says so
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "10"],
+                       capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["particles_conserved"] is True and out["transport_used"].startswith("peer (the RCCL run")
+    assert b"RCCL does not share a device" in r.stderr
     # a run that cannot start is reported, not raised
     bad = bench.peer_leg(os.path.join(ROOT, "no_such_program"), "dam", 2, argparse.Namespace(steps=1, warmup=0, workload="cfg2"))
     assert bad["status"].startswith("not started")
