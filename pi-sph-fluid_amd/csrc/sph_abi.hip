@@ -54,8 +54,10 @@ struct sph_ctx {
     bool velt_stale = false;     // the fused force pass does not store the velocity between steps: refresh_velt() before use
     bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
-    hipGraph_t graph[8] = {};          // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations)
-    hipGraphExec_t gexec[8] = {};
+    hipGraph_t graph[16] = {};         // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations); + 8: rest mode
+    hipGraphExec_t gexec[16] = {};
+    bool rest_mode = false;            // the step's graphs without a k_check launch (enqueue_step_body); decided in check_flags
+    uint32_t mode_steps = 0, mode_checks = 0;      // the step / check counters at the last decision
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
     bool one_launch_asked = false;  // sph_set_rebuild_launches(ctx, 1): the host vouches that nothing else computes on the device meanwhile
@@ -180,9 +182,10 @@ void refresh_velt(sph_ctx *ctx) {
 void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
-    if (!ctx->slab) launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2: do neighbouring waves still move together?
+    const bool rest = ctx->rest_mode && ctx->rebuild_wgs > 0 && !ev && !ctx->slab;      // (see check_flags)
+    if (!ctx->slab && !rest) launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2: do neighbouring waves still move together?
     if (ctx->rebuild_wgs > 0 && !ev) {
-        launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic);
+        launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, rest);
     } else {       // (the profiled step, and contexts that may share their device: one kernel per phase)
         launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
         if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
@@ -200,7 +203,7 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
 }
 
 void drop_graph(sph_ctx *ctx) {
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 16; k++) {
         if (ctx->gexec[k]) { (void)hipGraphExecDestroy(ctx->gexec[k]); ctx->gexec[k] = nullptr; }
         if (ctx->graph[k]) { (void)hipGraphDestroy(ctx->graph[k]); ctx->graph[k] = nullptr; }
     }
@@ -210,7 +213,7 @@ void drop_graph(sph_ctx *ctx) {
 // (launch-latency bound at small N; replay costs one submission)
 hipGraphExec_t step_graph(sph_ctx *ctx) {
     if (!ctx->use_graph) return nullptr;
-    const int k = ctx->a.pos == ctx->pos_a ? 0 : 1;
+    const int k = (ctx->a.pos == ctx->pos_a ? 0 : 1) + (ctx->rest_mode ? 8 : 0);
     if (ctx->gexec[k]) return ctx->gexec[k];
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
@@ -235,7 +238,7 @@ hipGraphExec_t step_graph(sph_ctx *ctx) {
 constexpr int MULTI_STEPS = 8;      // the largest; 4 and 2 serve the remainder of a call (20 steps = 8 + 8 + 4: three replays)
 hipGraphExec_t multi_graph(sph_ctx *ctx, int steps = MULTI_STEPS) {
     if (!ctx->use_graph || (steps != 8 && steps != 4 && steps != 2)) return nullptr;
-    const int k = (steps == 8 ? 6 : steps == 4 ? 4 : 2) + (ctx->a.pos == ctx->pos_a ? 0 : 1);
+    const int k = (steps == 8 ? 6 : steps == 4 ? 4 : 2) + (ctx->a.pos == ctx->pos_a ? 0 : 1) + (ctx->rest_mode ? 8 : 0);
     if (ctx->gexec[k]) return ctx->gexec[k];
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
@@ -263,7 +266,8 @@ hipGraphExec_t multi_graph(sph_ctx *ctx, int steps = MULTI_STEPS) {
 // them cost ~0.3 ms (a 20-step window measured 116 us per step where 1000 steps measure 94).
 void prebuild_graphs(sph_ctx *ctx) {
     if (ctx->slab || !ctx->use_graph || !fused(ctx)) return;
-    for (int o = 0; o < 2 && ctx->use_graph; o++) {
+    for (int o = 0; o < 4 && ctx->use_graph; o++) {      // both orientations, then both again in rest mode
+        if (o == 2) ctx->rest_mode = !ctx->rest_mode;
         hipGraphExec_t g = step_graph(ctx);
         if (g) (void)hipGraphUpload(g, ctx->stream);
         for (int m = MULTI_STEPS; m >= 2; m >>= 1) {
@@ -273,6 +277,7 @@ void prebuild_graphs(sph_ctx *ctx) {
         std::swap(ctx->a.pos, ctx->a.pos2);
         std::swap(ctx->a.vel, ctx->a.vel2);
     }
+    ctx->rest_mode = !ctx->rest_mode;      // (back to what it was)
     (void)hipGetLastError();
 }
 
@@ -316,6 +321,14 @@ int check_flags(sph_ctx *ctx) {
     uint32_t h[FLAG_COUNT] = {0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // Rest mode for the steps to come?  Yes if none of the (at least four) steps since the last decision had anybody beyond
+    // skin/2 (the relative check never ran): their graphs then hold no k_check launch and treat "beyond skin/2" as
+    // "rebuild" (k_rebuild).  No: the usual four kernels.  Decided wherever the host synchronises anyway.
+    if (!ctx->slab && h[FLAG_STEP] - ctx->mode_steps >= 4u) {
+        ctx->rest_mode = h[FLAG_NCHECK] == ctx->mode_checks;
+        ctx->mode_steps = h[FLAG_STEP];
+        ctx->mode_checks = h[FLAG_NCHECK];
+    }
     if (h[FLAG_BAR_TIMEOUT]) {
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_BAR_TIMEOUT, 0, sizeof(uint32_t), ctx->stream));
         ctx->rebuild_wgs = 0;

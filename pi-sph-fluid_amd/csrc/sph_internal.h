@@ -177,7 +177,8 @@ void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
 // between the phases: `grid` workgroups, all resident at once (rebuild_grid).  A no-op unless the rebuild word is set.
 int rebuild_grid(int device, int cap);
 // selftest: only the barriers (sph_create checks that they complete on this device before it relies on them)
-void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool selftest = false, bool deterministic = false);
+void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool selftest = false, bool deterministic = false,
+                    bool rest_mode = false);
 // slab mode, what follows the halo exchange, as one launch: ghost update, or (rebuild step) ingest -> scan -> scatter ->
 // canonical order of the interface cells -> tile records + lists
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag);

@@ -217,7 +217,8 @@ DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, ui
 // flow and leaves the skin alone.  Everything that depends on the skin is written here: the list cut-off (build_tile) and
 // the two thresholds of the rebuild criterion (drift_verdict, k_check).
 DEV void adapt_skin(const Consts &c, const uint32_t word, uint32_t *__restrict__ flags, float *__restrict__ dyn) {
-    const uint32_t step = flags[FLAG_STEP], last = flags[FLAG_LAST_REBUILD];
+    // (the step counter past the caches: in rest mode k_rebuild itself has counted this step a moment ago, after reading the same line)
+    const uint32_t step = __hip_atomic_load(&flags[FLAG_STEP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), last = flags[FLAG_LAST_REBUILD];
     float skin = dyn[DYN_SKIN];
     if (c.skin_min < c.skin_max && word == (uint32_t)REBUILD_CRITERION && last != 0u) {
         const float T = fmaxf((float)(step - last), 1.0f);

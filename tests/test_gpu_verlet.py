@@ -176,6 +176,37 @@ def test_skin_controller(sph, orc):
         assert direct == 0
 
 
+def test_rest_mode_steps_without_the_check_launch(sph, orc):
+    """After a synchronisation at which no step of the last interval needed the relative check, the step graphs hold no
+    k_check launch and k_rebuild treats "somebody beyond skin/2" as a rebuild request (sph_abi.hip, check_flags).  A tank
+    at rest stepped with such synchronisations equals the same tank stepped in one call (no rebuild in either: same bits);
+    a collapsing dam stepped with synchronisations stays exact (lists against the exact walk) and leaves rest mode again."""
+    prm, f, b = sph.scene_block((0.0, 30.6, 0.0, 8.0), 0.3, 0.3, 400, 60)
+    prm.deterministic = 1                   # (two contexts: the same bits only in the deterministic particle order)
+    with sph.Context(prm, f, b, GX, GY) as one:
+        one.step(120, GX, GY)
+        one.sync()
+        ref = one.read_particles()
+        r_one = one.rebuild_stats()[0]
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        for _ in range(12):
+            ctx.step(10, GX, GY)
+            ctx.sync()                      # (from the second chunk on: rest mode)
+        got = ctx.read_particles()
+        assert ctx.rebuild_stats()[0] == r_one and ctx.check_stats() == 0
+    for k in ("x", "y", "u", "v", "rho"):
+        assert np.array_equal(got[k], ref[k]), k
+    prm, f, b, g = block_scene(sph, orc, None)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        done = 0
+        for k in (6, 12, 60, 200, 400):
+            ctx.step(k - done, GX, GY)
+            done = k
+            ctx.sync()
+            lists_vs_exact_walk(ctx, ("rest mode", k))
+        assert ctx.check_stats() > 0 and ctx.rebuild_stats()[1] == 0
+
+
 def test_coherent_motion_keeps_lists(sph, orc, oracle):
     """a block moving as a whole at 30 m/s (0.5 skin/2 per step at the default skin): the absolute criterion would
     rebuild every other step; the relative one (per-wave displacement boxes) keeps the lists for many steps.  Results
