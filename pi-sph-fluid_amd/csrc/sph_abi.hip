@@ -523,7 +523,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     {   // the skin the first lists are built with (adapt_skin derives the thresholds from it at the first rebuild): the
         // smallest — most scenes start at rest, and the first rebuild the flow itself asks for corrects it
         const Consts &c = ctx->c;
-        const float hdyn[DYN_COUNT] = {0.0f, 0.0f, 0.0f, c.skin_min};
+        const float hdyn[DYN_COUNT] = {0.0f, 0.0f, 0.0f, c.skin_min, 0.0f, 0.0f};
+        a.uref = ctx->slab ? nullptr : a.dyn + DYN_UREF_X;      // (slabs: the absolute criterion — their references would differ)
         HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
     }
 

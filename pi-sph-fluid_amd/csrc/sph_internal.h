@@ -98,6 +98,7 @@ struct Arrays {
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
+    float *uref;        // where the density pass leaves the reference displacement (dyn + DYN_UREF_X; nullptr: slab contexts)
     float *dyn;         // DYN_COUNT floats: the list cut-off and the rebuild thresholds that follow from the current skin
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
     // slab halo buffers: uint32 header[4] = {count,..} + halo_cap records of 5 words (x, y, u, v, id)
@@ -133,7 +134,9 @@ enum {
     DYN_LIM2 = 1,           // (skin/2)^2 : while nobody is further than this from its rebuild position the lists are valid
     DYN_SKIN2 = 2,          // skin^2     : ... and beyond that, while neighbouring waves moved less than this RELATIVE to each other (k_check)
     DYN_SKIN = 3,           // the skin [m] of the present lists
-    DYN_COUNT = 4
+    DYN_UREF_X = 4,         // the reference displacement of this step (single-GPU contexts; slabs: 0): criterion (0) is
+    DYN_UREF_Y = 5,         //   |u_i - U| <= skin/2 for ANY common U (then |u_i - u_k| <= skin) — see drift_verdict
+    DYN_COUNT = 6
 };
 // the rebuild word: 0 = no rebuild; REBUILD_CRITERION = the displacement criterion asked for it (the interval since the last
 // rebuild then steers the skin); REBUILD_HOST = the host did (creation, upload, sph_request_rebuild: says nothing about the flow)

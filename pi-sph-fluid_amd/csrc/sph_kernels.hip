@@ -130,7 +130,12 @@ DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group
                        uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild, const float *__restrict__ dyn) {
     static_assert(BOXG == 64, "a box group is a wave");
     const float d2 = fmaf(ux, ux, uy * uy);
-    const bool over = live && !(d2 <= dyn[DYN_LIM2]);      // true for NaN too
+    // Criterion (0) relative to a displacement U that is the same for every particle of this launch: if everybody is within
+    // skin/2 of U, no two particles have moved more than the skin relative to each other — whatever U is.  U = 0 is the
+    // absolute form; the density pass of the step leaves the (predicted) displacement of three sampled particles' median
+    // there, so a fluid that moves as a whole (a falling drop) does not raise the check word step after step.
+    const float rx = ux - dyn[DYN_UREF_X], ry = uy - dyn[DYN_UREF_Y];
+    const bool over = live && !(fmaf(rx, rx, ry * ry) <= dyn[DYN_LIM2]);      // true for NaN too
     const bool capped = live && !(d2 <= c.cap2);
     const float inf = __builtin_huge_valf();
     const float x0 = group_min(live ? ux : inf), y0 = group_min(live ? uy : inf);

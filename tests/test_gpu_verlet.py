@@ -229,8 +229,11 @@ def test_coherent_motion_keeps_lists(sph, orc, oracle):
         r1, _ = ctx.rebuild_stats()
         checks = ctx.check_stats()
     assert max(np.abs(got["x"] - of["x"]).max(), np.abs(got["y"] - of["y"]).max()) <= 1e-4
-    assert checks >= 140                      # the block moved more than skin/2 within two steps ...
-    assert r1 - r0 <= 40, (r0, r1)            # ... but it moved together: few rebuilds (absolute criterion: ~75)
+    # the block moved more than skin/2 within two steps, but it moved together: criterion (0) is taken relative to the
+    # displacement of sampled particles (drift_verdict), so the relative check is needed only once the collapse has distorted
+    # the block, and there are few rebuilds (absolute criterion: ~75)
+    assert checks < 140, checks
+    assert r1 - r0 <= 40, (r0, r1)
 
 
 @pytest.mark.parametrize("one_launch", [True, False])
