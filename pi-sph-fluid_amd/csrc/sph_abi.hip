@@ -57,6 +57,7 @@ struct sph_ctx {
     hipGraph_t graph[16] = {};         // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations); + 8: rest mode
     hipGraphExec_t gexec[16] = {};
     bool rest_mode = false;            // the step's graphs without a k_check launch (enqueue_step_body); decided in check_flags
+    int rest_left = 0;                 // ... for this many more steps (REST_STEPS after a decision: a stale "at rest" costs little)
     uint32_t mode_steps = 0, mode_checks = 0;      // the step / check counters at the last decision
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
@@ -317,6 +318,7 @@ int resort_state(sph_ctx *ctx) {
     return SPH_OK;
 }
 
+constexpr int REST_STEPS = 64;      // steps in rest mode after a synchronisation that found the fluid at rest
 int check_flags(sph_ctx *ctx) {
     uint32_t h[FLAG_COUNT] = {0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -325,7 +327,8 @@ int check_flags(sph_ctx *ctx) {
     // skin/2 (the relative check never ran): their graphs then hold no k_check launch and treat "beyond skin/2" as
     // "rebuild" (k_rebuild).  No: the usual four kernels.  Decided wherever the host synchronises anyway.
     if (!ctx->slab && h[FLAG_STEP] - ctx->mode_steps >= 4u) {
-        ctx->rest_mode = h[FLAG_NCHECK] == ctx->mode_checks;
+        ctx->rest_left = h[FLAG_NCHECK] == ctx->mode_checks ? REST_STEPS : 0;
+        ctx->rest_mode = ctx->rest_left > 0;
         ctx->mode_steps = h[FLAG_STEP];
         ctx->mode_checks = h[FLAG_NCHECK];
     }
@@ -643,6 +646,7 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     int s = 0;
     while (s < nsteps) {
+        ctx->rest_mode = ctx->rest_left > 0;      // (which set of graphs: check_flags)
         if (fused(ctx) && ctx->primed && nsteps - s >= 2) {
             const int m = nsteps - s >= 8 ? 8 : nsteps - s >= 4 ? 4 : 2;
             hipGraphExec_t g = multi_graph(ctx, m);
@@ -651,13 +655,16 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
                 ctx->velt_stale = true;
                 ctx->p_stale = true;
                 s += m;
+                ctx->rest_left = ctx->rest_left > m ? ctx->rest_left - m : 0;
                 continue;
             }
         }
         int rc = run_step(ctx, nullptr);
         if (rc) return rc;
         s++;
+        ctx->rest_left = ctx->rest_left > 1 ? ctx->rest_left - 1 : 0;
     }
+    ctx->rest_mode = ctx->rest_left > 0;
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
