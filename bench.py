@@ -517,7 +517,10 @@ def main():
         "kernel_ms": {k: (v if isinstance(v, list) else round(v, 5)) for k, v in res["kernel_ms"].items()},
         "neighbour_rebuilds_per_step": round(res["timed_rebuilds_per_step"], 4), "skin_fraction_of_2h": round(res["skin_frac"], 4),
         "skin_min_fraction_of_2h": round(res["skin_min_frac"], 4), "skin_at_end_fraction_of_2h": round(res["skin_now"], 4),
-        "roofline": roofline(sph, res, "cfg2_developed" if args.workload == "cfg2" and args.warmup >= 3000 else None),
+        # (the PMC traffic of the regime the window is in: steps 4000+ = the developed flow; the first ~100 steps = the fluid at
+        # rest with the smallest skin — the driver's `--steps 20 --warmup 5`; otherwise the early collapse of steps 100-400)
+        "roofline": roofline(sph, res, None if args.workload != "cfg2" else "cfg2_developed" if args.warmup >= 3000 else
+                             "cfg2_at_rest" if args.warmup + args.steps <= 100 else None),
     }
 
     def also_entry(label, r, traffic_key):
