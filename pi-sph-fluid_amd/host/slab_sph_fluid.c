@@ -485,6 +485,7 @@ typedef struct rank_state {
     sph_params prm;
     comm cm;
     int device, transport, deterministic, capacity;
+    int own_device;              /* no other rank of this run on this rank's device (peer: as many devices as ranks) */
     sph_particle *walls;
     long nw;
     hipStream_t st, xst;
@@ -576,7 +577,7 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
     SPHCHK(rs->ctx, sph_set_stream(rs->ctx, rs->st));
     /* one rank per GPU (rccl): nothing else computes on this device, so what follows the halo exchange may run as one
      * launch with grid barriers (include/sph.h, sph_set_rebuild_launches); ranks that may share a device must not */
-    if (rs->transport == TR_RCCL) SPHCHK(rs->ctx, sph_set_rebuild_launches(rs->ctx, 1));
+    if (rs->transport == TR_RCCL || (rs->transport == TR_PEER && rs->own_device)) SPHCHK(rs->ctx, sph_set_rebuild_launches(rs->ctx, 1));
     if (rs->transport == TR_PEER) {      /* the context sends from and receives into this rank's block */
         char *b = (char *)rs->peer_blk;
         SPHCHK(rs->ctx, sph_slab_set_buffers(rs->ctx, b, b + rs->peer_halo, b + peer_off_recv(rs, 0), b + peer_off_recv(rs, 1), rs->peer_halo));
@@ -856,6 +857,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     rs.device = transport == TR_RCCL ? rank : rank % ndev;
+    rs.own_device = nranks <= ndev;
     HIPCHK(hipSetDevice(rs.device));
     HIPCHK(hipStreamCreateWithFlags(&rs.st, hipStreamNonBlocking));      /* compute stream (adopted by the context) ... */
     HIPCHK(hipStreamCreateWithFlags(&rs.xst, hipStreamNonBlocking));     /* ... and exchange stream */
