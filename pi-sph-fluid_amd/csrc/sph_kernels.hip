@@ -128,7 +128,7 @@ DEV float group_max(float v) {
 // without a live lane leaves an empty box (zero displacement): in slab mode k_check may look at it (see there).
 DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group, float4 *__restrict__ wbox,
                        uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild, const float *__restrict__ dyn) {
-    static_assert(BOXG == 64, "a box group is a wave");
+    static_assert(BOXG == 64 || BOXG == 32 || BOXG == 16, "a box group is a wave or an aligned part of one");
     const float d2 = fmaf(ux, ux, uy * uy);
     // Criterion (0) relative to a displacement U that is the same for every particle of this launch: if everybody is within
     // skin/2 of U, no two particles have moved more than the skin relative to each other — whatever U is.  U = 0 is the
@@ -140,8 +140,10 @@ DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group
     const float inf = __builtin_huge_valf();
     const float x0 = group_min(live ? ux : inf), y0 = group_min(live ? uy : inf);
     const float x1 = group_max(live ? ux : -inf), y1 = group_max(live ? uy : -inf);
-    const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped), any_live = __ballot(live);
-    if ((threadIdx.x & 63) == 0) {
+    const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped);
+    const unsigned long long gmask = (BOXG == 64 ? ~0ull : ((1ull << (BOXG & 63)) - 1ull)) << (threadIdx.x & 63 & ~(BOXG - 1));
+    const unsigned long long any_live = __ballot(live) & gmask;      // (the live lanes of THIS group)
+    if ((threadIdx.x & (BOXG - 1)) == 0) {
         wbox[group] = any_live != 0ull ? make_float4(x0, y0, x1, y1) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (any_over != 0ull) *check = 1u;
         if (any_cap != 0ull) atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);
