@@ -182,6 +182,9 @@ int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_til
  * neighbour list longer than the list capacity; and [6] workgroups of one-launch rebuilds that did not run on the XCD of
  * their grid-barrier leader and took the slow path (measurement / diagnostics) */
 int   sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]);
+/* pairs of box groups whose particles were checked one by one (instead of a rebuild) because their boxes had moved more
+ * than the skin relative to each other (single-GPU contexts; see k_check in csrc/sph_kernels.hip) */
+int  sph_verify_stats(sph_ctx *ctx, long long *pairs);
 /* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
 int   sph_check_stats(sph_ctx *ctx, long long *checks);
 /* total particles clamped into the domain so far (0 in a healthy run) */

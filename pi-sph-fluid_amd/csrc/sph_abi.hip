@@ -184,7 +184,10 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
     const bool rest = ctx->rest_mode && ctx->rebuild_wgs > 0 && !ev && !ctx->slab;      // (see check_flags)
-    if (!ctx->slab && !rest) launch_check(st, ctx->c, ctx->a, ctx->cap);      // beyond skin/2: do neighbouring waves still move together?
+    // beyond skin/2: do neighbouring groups still move together?  (their failing pairs are verified by the one-launch rebuild)
+    const bool verify = !ctx->slab && !rest && ctx->rebuild_wgs > 0 && !ev && ctx->c.skin_max > 0.0f;
+    if (!ctx->slab && !rest) launch_check(st, ctx->c, ctx->a, ctx->cap, nullptr, verify);
+    if (verify) launch_verify(st, ctx->c, ctx->a);
     if (ctx->rebuild_wgs > 0 && !ev) {
         launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, rest);
     } else {       // (the profiled step, and contexts that may share their device: one kernel per phase)
@@ -485,6 +488,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4); ALLOC(a.dyn, DYN_COUNT);
+    a.vq = nullptr;
+    if (!slab) { ALLOC(a.vq, 2 + 2 * (size_t)VQ_CAP); }
     ALLOC(a.gbar, (size_t)GBAR_WORDS * GBAR_STRIDE);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 1024);
     ALLOC(ctx->d_ids, n);
@@ -528,6 +533,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         const Consts &c = ctx->c;
         const float hdyn[DYN_COUNT] = {0.0f, 0.0f, 0.0f, c.skin_min, 0.0f, 0.0f};
         a.uref = ctx->slab ? nullptr : a.dyn + DYN_UREF_X;      // (slabs: the absolute criterion — their references would differ)
+        if (a.vq) HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (2 + 2 * (size_t)VQ_CAP), st));
         HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
     }
 
@@ -824,6 +830,16 @@ int sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]) {
     for (int k = 0; k < 7; k++) why[k] = h[k];
     return SPH_OK;
 }
+int sph_verify_stats(sph_ctx *ctx, long long *pairs) {
+    if (!ctx || !ctx->stream || !pairs) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    uint32_t h = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h, ctx->a.flags + FLAG_NVERIFY, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *pairs = h;
+    return SPH_OK;
+}
+
 int sph_check_stats(sph_ctx *ctx, long long *checks) {
     if (!ctx || !ctx->stream || !checks) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);

@@ -98,6 +98,7 @@ struct Arrays {
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
+    uint32_t *vq;       // verification queue (k_check -> k_rebuild): [0] count, [2 + 2 e ..] = (group, failing neighbour group); nullptr: slabs
     float *uref;        // where the density pass leaves the reference displacement (dyn + DYN_UREF_X; nullptr: slab contexts)
     float *dyn;         // DYN_COUNT floats: the list cut-off and the rebuild thresholds that follow from the current skin
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
@@ -125,8 +126,10 @@ enum {
     FLAG_OFF_XCD = 19,      // workgroups of one-launch rebuilds so far that did not run on the XCD of their barrier leader
     FLAG_STEP = 20,         // steps so far (k_check counts them)
     FLAG_LAST_REBUILD = 21, // FLAG_STEP at the last rebuild
+    FLAG_NVERIFY = 23,      // pairs of box groups that k_check verified particle by particle instead of asking for a rebuild
     FLAG_PEER_DONE = 22,    // workgroups of k_peer_push that have finished (grows: the last one of a launch raises the flags)
-    FLAG_COUNT = 23
+    FLAG_BAR_EPOCH = 24,    // launches that used grid barriers so far (the barrier words only grow: 8 values per such launch)
+    FLAG_COUNT = 25
 };
 // Arrays::dyn
 enum {
@@ -160,6 +163,7 @@ constexpr int LIST_WORDS_PER_TILE = 12 * SPH_TILE_PARTICLES;   // LROWS4 x TP (s
 constexpr int XRANGE_WORDS = 260;                              // 4 RMAX + 1 prefix sums, 4 RMAX first particles (sph_list.inc)
 constexpr int STAB_ENTRIES_PER_TILE = 896;                     // staging-table entries per tile (sph_list.inc)
 constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle list padding points at (finite: no NaN)
+constexpr int VQ_CAP = 4096;    // pairs of groups the verification queue holds (more: rebuild)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record
 
@@ -207,7 +211,8 @@ void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int c
 // single GPU: if the check word is set, compare the displacement boxes of neighbouring waves; raise the rebuild word
 // when two of them moved more than the skin relative to each other
 // gravity != nullptr: (gx, gy) of this step, written to the device by the same launch (slab step)
-void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity = nullptr);
+void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity = nullptr, bool verify = false);
+void launch_verify(hipStream_t st, const Consts &c, const Arrays &a);
 // rebuild kernels (no-ops unless flags[FLAG_REBUILD]): scan, scatter, tile records + neighbour lists
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
                  uint32_t *block_sums, const uint32_t *rebuild, bool reduce);

@@ -72,7 +72,9 @@ def test_reused_lists_equal_exact_walk(sph, orc, frac):
         if frac is not None:
             assert skins == {round(frac, 4)}, skins  # a fixed skin stays
         if frac is not None and frac <= 0.05:
-            assert r1 - r0 > 0, (r0, r1)             # a thin skin cannot survive 400 steps of a collapsing dam
+            # a thin skin cannot survive 400 steps of a collapsing dam on the box criterion alone: either the lists were
+            # rebuilt, or pairs of groups whose boxes had failed were verified particle by particle and found complete
+            assert r1 - r0 > 0 or ctx.verify_stats() > 0, (r0, r1, ctx.verify_stats())
         assert direct == 0
 
 
@@ -172,7 +174,7 @@ def test_skin_controller(sph, orc):
         ctx.sync()
         lists_vs_exact_walk(ctx, "tank")
         r, direct = ctx.rebuild_stats()
-        assert r >= 3 and abs(ctx.current_skin() - prm.skin_min) <= 1e-6, (ctx.current_skin(), r)      # asked twice, stayed
+        assert r >= 2 and abs(ctx.current_skin() - prm.skin_min) <= 1e-6, (ctx.current_skin(), r)      # asked, stayed
         assert direct == 0
 
 
@@ -287,16 +289,19 @@ def test_deterministic_runs_are_bit_identical(sph, orc):
     f = particles(orc, np.concatenate([xy, np.zeros_like(xy)], 1), m_fluid(prm))
     b = boundary_particles(orc, g["boundary_xy"])
     runs = []
-    for one_launch in (True, False, True):
+    for one_launch in (True, True, False, False):
         with sph.Context(prm, f, b, GX, GY) as ctx:
             ctx.set_rebuild_launches(one_launch)
             a0 = ctx.read_accel()
             ctx.step(400, GX, GY)
             ctx.sync()
-            runs.append((ctx.read_particles(), ctx.read_accel(), a0, ctx.rebuild_stats()[0]))
-    for got, acc, a0, reb in runs[1:]:
+            runs.append((ctx.read_particles(), ctx.read_accel(), a0, ctx.rebuild_stats()[0], ctx.verify_stats()))
+    # (the two launch modes rebuild in different steps — only the one-launch rebuild verifies failing pairs of groups particle
+    # by particle instead of rebuilding — so each mode is compared with itself)
+    for first, second in ((0, 1), (2, 3)):
+        got, acc, a0, reb, ver = runs[second]
         for k in ("x", "y", "u", "v", "rho", "p"):
-            assert np.array_equal(got[k], runs[0][0][k]), k
-        assert np.array_equal(acc[0], runs[0][1][0]) and np.array_equal(acc[1], runs[0][1][1])
-        assert np.array_equal(a0[0], runs[0][2][0]) and reb == runs[0][3]
-    assert runs[0][3] > 3
+            assert np.array_equal(got[k], runs[first][0][k]), (k, first)
+        assert np.array_equal(acc[0], runs[first][1][0]) and np.array_equal(acc[1], runs[first][1][1])
+        assert np.array_equal(a0[0], runs[first][2][0]) and reb == runs[first][3] and ver == runs[first][4]
+    assert runs[2][3] > 3 and runs[2][4] == 0 and runs[0][4] > 0      # per phase: rebuilds, no verification; one launch: verification
