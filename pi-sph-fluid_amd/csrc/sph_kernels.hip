@@ -370,14 +370,19 @@ DEV bool verify_groups(const Consts &c, const int w, const int h, const int n, c
     // (both thresholds on the safe side of the rounding: "not listed" a little early, "inside the support" a little early)
     const float not_listed = cut_list2 * 0.999999f, inside = c.cut2 * 1.000001f;
     bool hit = false;
-#pragma unroll 4
+    const int iqv = vq ? iq : -1;
+    // (the q's by v_readlane with constant lanes — scalar operands of the compares; as ds_bpermute shuffles this loop was 8 us)
+#pragma unroll
     for (int j = 0; j < 64; j++) {
-        const float qx = __shfl(xq.x, j, 64), qy = __shfl(xq.y, j, 64), sx = __shfl(rq.x, j, 64), sy = __shfl(rq.y, j, 64);
-        const int qi = __shfl(vq ? iq : -1, j, 64);
+        const float qx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(xq.x), j));
+        const float qy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(xq.y), j));
+        const float sx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rq.x), j));
+        const float sy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rq.y), j));
+        const int qi = __builtin_amdgcn_readlane(iqv, j);
         const float ex = rp.x - sx, ey = rp.y - sy, dx = xp.x - qx, dy = xp.y - qy;
-        hit |= vp && qi >= 0 && qi != ip && fmaf(ex, ex, ey * ey) >= not_listed && fmaf(dx, dx, dy * dy) < inside;
+        hit |= qi >= 0 && qi != ip && fmaf(ex, ex, ey * ey) >= not_listed && fmaf(dx, dx, dy * dy) < inside;
     }
-    return __any(hit) != 0;
+    return __any(hit && vp) != 0;
 }
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                                                const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(BLK) void k_verify(Consts c, const uint32_t *__rest
 }
 void launch_verify(hipStream_t st, const Consts &c, const Arrays &a) {
     if (!a.vq) return;
-    hipLaunchKernelGGL(k_verify, dim3(256), dim3(BLK), 0, st, c, a.vq, a.rebuild, a.flags, a.dn, a.dyn, a.lrec, a.pos, a.pos_ref);
+    hipLaunchKernelGGL(k_verify, dim3(512), dim3(BLK), 0, st, c, a.vq, a.rebuild, a.flags, a.dn, a.dyn, a.lrec, a.pos, a.pos_ref);
 }
 // verify: k_verify follows and checks what this kernel queues (otherwise failing boxes ask for the rebuild)
 void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, bool verify) {
