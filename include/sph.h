@@ -182,9 +182,16 @@ int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_til
  * neighbour list longer than the list capacity; and [6] workgroups of one-launch rebuilds that did not run on the XCD of
  * their grid-barrier leader and took the slow path (measurement / diagnostics) */
 int   sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]);
+/* Verification of failing box pairs (k_verify; one more launch per step): mode -1 = automatic (from 500 000 particles on, where
+ * a rebuild costs far more than a launch), 0 = never, 1 = always.  Single-GPU contexts with the one-launch rebuild and skin > 0. */
+int  sph_set_verification(sph_ctx *ctx, int mode);
 /* pairs of box groups whose particles were checked one by one (instead of a rebuild) because their boxes had moved more
  * than the skin relative to each other (single-GPU contexts; see k_check in csrc/sph_kernels.hip) */
 int  sph_verify_stats(sph_ctx *ctx, long long *pairs);
+/* who asked for the rebuilds so far (requests, several may ask for the same rebuild): why[0] box pairs that could not be verified
+ * (too many failing neighbours of one group, the queue full, or a mode without verification), why[1] the verification found a
+ * pair missing from the lists, why[2] a particle drifted H + skin from its sort position, why[3] rest mode: beyond skin/2 */
+int  sph_rebuild_reasons(sph_ctx *ctx, long long why[4]);
 /* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
 int   sph_check_stats(sph_ctx *ctx, long long *checks);
 /* total particles clamped into the domain so far (0 in a healthy run) */

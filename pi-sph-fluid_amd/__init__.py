@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_set_boundary_velocity", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
     "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_get_rebuild_launches", "sph_rebuild_stats", "sph_check_stats",
-    "sph_direct_tile_reasons", "sph_current_skin", "sph_verify_stats",
+    "sph_direct_tile_reasons", "sph_current_skin", "sph_verify_stats", "sph_rebuild_reasons", "sph_set_verification",
     "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
     "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
     "sph_render_metaballs",
@@ -145,6 +145,7 @@ def hip_lib():
         L.sph_rebuild_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.sph_check_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.sph_verify_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
+        L.sph_rebuild_reasons.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.sph_direct_tile_reasons.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.sph_current_skin.argtypes = [vp]
         L.sph_current_skin.restype = C.c_float
@@ -455,6 +456,16 @@ class Context:
         a, b = C.c_longlong(), C.c_longlong()
         self._chk(self.L.sph_rebuild_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_verification(self, mode):
+        """True / False / None (automatic: from 500 000 particles on) — failing box pairs verified particle by particle (k_verify)."""
+        self._chk(self.L.sph_set_verification(self.h, -1 if mode is None else (1 if mode else 0)))
+
+    def rebuild_reasons(self):
+        """(unverifiable box pairs, verification found a missing pair, drift cap, rest mode) — requests for a rebuild so far."""
+        a = (C.c_longlong * 4)()
+        self._chk(self.L.sph_rebuild_reasons(self.h, a))
+        return tuple(int(v) for v in a)
 
     def verify_stats(self):
         """pairs of box groups verified particle by particle so far (instead of asking for a rebuild)."""

@@ -57,6 +57,7 @@ struct sph_ctx {
     hipGraph_t graph[16] = {};         // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations); + 8: rest mode
     hipGraphExec_t gexec[16] = {};
     bool rest_mode = false;            // the step's graphs without a k_check launch (enqueue_step_body); decided in check_flags
+    int verify_mode = -1;              // k_check queues + k_verify: -1 = from VERIFY_MIN_PARTICLES on, 0 = never, 1 = always (sph_set_verification)
     int rest_left = 0;                 // ... for this many more steps (REST_STEPS after a decision: a stale "at rest" costs little)
     uint32_t mode_steps = 0, mode_checks = 0;      // the step / check counters at the last decision
     bool use_graph = true;
@@ -180,12 +181,16 @@ void refresh_velt(sph_ctx *ctx) {
 // What a step launches after its kick/drift (SPH_K_* order; ev != nullptr records an event before each): the rebuild
 // kernels (no-ops unless requested), density + EOS, force + kick.  With the list kernels the force pass also
 // integrates the next step's kick 1/2 + drift (FORCE_KICK_DRIFT).
+constexpr int VERIFY_MIN_PARTICLES = 500000;      // k_check queues + k_verify from this many particles on
 void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
     const bool rest = ctx->rest_mode && ctx->rebuild_wgs > 0 && !ev && !ctx->slab;      // (see check_flags)
     // beyond skin/2: do neighbouring groups still move together?  (their failing pairs are verified by the one-launch rebuild)
-    const bool verify = !ctx->slab && !rest && ctx->rebuild_wgs > 0 && !ev && ctx->c.skin_max > 0.0f;
+    // (the verification is a launch more per step, ~3 us: it pays where a rebuild is expensive, i.e. with many particles —
+    // 262 144 particles, cfg1: 43.5k -> 38k steps/s with it; 2 000 000, cfg2: +9 % in the protocol's median window)
+    const bool verify = !ctx->slab && !rest && ctx->rebuild_wgs > 0 && !ev && ctx->c.skin_max > 0.0f &&
+                        (ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0);
     if (!ctx->slab && !rest) launch_check(st, ctx->c, ctx->a, ctx->cap, nullptr, verify);
     if (verify) launch_verify(st, ctx->c, ctx->a);
     if (ctx->rebuild_wgs > 0 && !ev) {
@@ -830,6 +835,26 @@ int sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]) {
     for (int k = 0; k < 7; k++) why[k] = h[k];
     return SPH_OK;
 }
+int sph_set_verification(sph_ctx *ctx, int mode) {
+    if (!ctx || !ctx->stream || mode < -1 || mode > 1) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_set_verification: single-GPU contexts only");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->verify_mode = mode;
+    drop_graph(ctx);      // (the captured steps hold or do not hold the k_verify launch)
+    return SPH_OK;
+}
+
+int sph_rebuild_reasons(sph_ctx *ctx, long long why[4]) {
+    if (!ctx || !ctx->stream || !why) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    uint32_t h[4] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags + FLAG_WHY_REBUILD, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; k++) why[k] = h[k];
+    return SPH_OK;
+}
+
 int sph_verify_stats(sph_ctx *ctx, long long *pairs) {
     if (!ctx || !ctx->stream || !pairs) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);

@@ -129,7 +129,11 @@ enum {
     FLAG_NVERIFY = 23,      // pairs of box groups that k_check verified particle by particle instead of asking for a rebuild
     FLAG_PEER_DONE = 22,    // workgroups of k_peer_push that have finished (grows: the last one of a launch raises the flags)
     FLAG_BAR_EPOCH = 24,    // launches that used grid barriers so far (the barrier words only grow: 8 values per such launch)
-    FLAG_COUNT = 25
+    FLAG_WHY_REBUILD = 25,  // who asked for the rebuilds (4 counters of requests, not of rebuilds): 0 the box check could not be
+                            //   verified (a lane with too many failing neighbours, the queue full, no verification in this mode),
+                            //   1 the verification found a pair missing from the lists, 2 somebody drifted H + skin from its sort
+                            //   position (the cap), 3 rest mode: somebody beyond skin/2
+    FLAG_COUNT = 29
 };
 // Arrays::dyn
 enum {

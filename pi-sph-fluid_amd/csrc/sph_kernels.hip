@@ -146,7 +146,10 @@ DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group
     if ((threadIdx.x & (BOXG - 1)) == 0) {
         wbox[group] = any_live != 0ull ? make_float4(x0, y0, x1, y1) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (any_over != 0ull) *check = 1u;
-        if (any_cap != 0ull) atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);
+        if (any_cap != 0ull) {
+            atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);
+            atomicAdd(check + ((int)FLAG_WHY_REBUILD + 2 - (int)FLAG_CHECK), 1u);      // (the check word always lives in flags[])
+        }
     }
 }
 
@@ -433,7 +436,10 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
                 hard = true;      // the queue is full: the rebuild it is
             }
         }
-        if (hard) atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);      // (never lowers a host's request)
+        if (hard) {
+            atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);      // (never lowers a host's request)
+            atomicAdd(&flags[FLAG_WHY_REBUILD + 0], 1u);
+        }
     }
 }
 // returns true: rebuild (no verification possible or allowed); false: fine, or up to VERIFY_MAX failing neighbour groups in fail_h
@@ -497,7 +503,10 @@ __global__ __launch_bounds__(BLK) void k_verify(Consts c, const uint32_t *__rest
         const uint2 pr = reinterpret_cast<const uint2 *>(vq + 2)[e];
         stale |= verify_groups(c, (int)pr.x, (int)pr.y, n, lrec, pos, pos_ref, cut_list2);
     }
-    if (stale && (threadIdx.x & 63u) == 0u) atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);
+    if (stale && (threadIdx.x & 63u) == 0u) {
+        atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);
+        atomicAdd(&flags[FLAG_WHY_REBUILD + 1], 1u);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_NVERIFY], nverify);
 }
 void launch_verify(hipStream_t st, const Consts &c, const Arrays &a) {

@@ -54,6 +54,7 @@ def test_reused_lists_equal_exact_walk(sph, orc, frac):
     """(None: the library default, a skin that adapts between skin_min and skin to how long the lists last)"""
     prm, f, b, g = block_scene(sph, orc, frac)
     with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.set_verification(True)      # (automatic only from 500 000 particles on: here the lists' checks below cover it)
         rows, cols, cell = ctx.device_grid()
         assert abs(cell - 2 * prm.h * (1 + prm.skin)) <= 1e-6      # the grid is sized for the largest skin
         assert prm.skin_min - 1e-6 <= ctx.current_skin() <= prm.skin + 1e-6
@@ -145,6 +146,37 @@ def test_fast_random_particles(sph, orc):
                 lists_vs_exact_walk(ctx, (frac, k))
             got = ctx.read_particles()
             assert np.all(np.isfinite(got["x"])) and np.all(np.isfinite(got["rho"]))
+
+
+def test_verification_instead_of_rebuilds(sph, orc):
+    """k_verify: the pairs of box groups whose boxes have moved more than the skin relative to each other are checked particle
+    by particle, and the lists are rebuilt only when a pair that is in nobody's list has come inside the support.  The same
+    collapsing dam with and without it: the lists complete at every look (against the exact walk) in both; fewer rebuilds
+    and some verified pairs with it; skin 0 keeps rebuilding every step (sph_set_verification has no effect there)."""
+    res = {}
+    for on in (False, True):
+        prm, f, b, g = block_scene(sph, orc, 0.1)
+        with sph.Context(prm, f, b, GX, GY) as ctx:
+            ctx.set_verification(on)
+            r0 = ctx.rebuild_stats()[0]
+            done = 0
+            for k in (30, 90, 200, 400, 700, 1000):
+                ctx.step(k - done, GX, GY)
+                done = k
+                ctx.sync()
+                lists_vs_exact_walk(ctx, (on, k))
+            res[on] = (ctx.rebuild_stats()[0] - r0, ctx.verify_stats(), ctx.rebuild_reasons())
+            assert ctx.rebuild_stats()[1] == 0
+    assert res[False][1] == 0 and res[True][1] > 0, res
+    assert res[True][0] < res[False][0], res
+    assert res[False][2][1] == 0                                   # nobody verified, nothing found stale by verification
+    prm, f, b, g = block_scene(sph, orc, 0.0)
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.set_verification(True)
+        r0 = ctx.rebuild_stats()[0]
+        ctx.step(30, GX, GY)
+        ctx.sync()
+        assert ctx.rebuild_stats()[0] - r0 == 30 and ctx.verify_stats() == 0
 
 
 def test_skin_controller(sph, orc):
@@ -292,6 +324,7 @@ def test_deterministic_runs_are_bit_identical(sph, orc):
     for one_launch in (True, True, False, False):
         with sph.Context(prm, f, b, GX, GY) as ctx:
             ctx.set_rebuild_launches(one_launch)
+            ctx.set_verification(True)      # (works with the one-launch rebuild only; this scene is below the automatic limit)
             a0 = ctx.read_accel()
             ctx.step(400, GX, GY)
             ctx.sync()
