@@ -163,7 +163,8 @@ int  sph_device_grid(const sph_ctx *ctx, int *rows, int *cols, float *cell);
  * 2H + skin) serves density and force, and stays in use while it is provably complete: as long as every particle is
  * within skin/2 of where it was at the rebuild, or — single GPU — as long as no two particles whose cells were at
  * most two cells apart have moved more than the skin RELATIVE to each other (checked on per-wave displacement boxes,
- * so a jet moving as a whole keeps its lists) and nobody has moved more than H + skin.  Until then no unlisted pair
+ * so a jet moving as a whole keeps its lists; where two boxes fail that bound, their particles are checked pair by pair
+ * before a rebuild is asked for: sph_set_verification) and nobody has moved more than H + skin.  Until then no unlisted pair
  * can be inside the support 2H, and listed pairs beyond 2H contribute exactly 0.  Results do not depend on the skin
  * (beyond summation order).  skin = 0: a rebuild whenever neighbouring particles moved relative to each other at all.
  * The skin is a fraction of 2H between sph_params.skin_min and sph_params.skin (0 <= skin <= 1), chosen by the device at
