@@ -80,28 +80,6 @@ typedef struct sph_params {
 
 typedef struct sph_ctx sph_ctx;
 
-/* names of the per-step kernels, in launch order (index into sph_kernel_times.ms).  The kernels marked [R] are
- * the rebuild of the neighbour structure (the reference's update_neighbors_context :104-124 + find_neighbors
- * :126-153): they return at once unless a rebuild was asked for.  sph_step launches them as ONE kernel with grid
- * barriers between the phases (sph_set_rebuild_launches); sph_profile_steps, which times them one by one, as four. */
-enum {
-    SPH_K_KICK_DRIFT     = 0,  /* :615-624 in place; requests a rebuild when a particle moved > skin/2 since the last */
-    SPH_K_KEY_HIST       = 1,  /* [R] cell index of :111-113 + histogram (counting sort pass 1)      */
-    SPH_K_SCAN           = 2,  /* [R] counting sort: exclusive scan -> cell_start                    */
-    SPH_K_REORDER        = 3,  /* [R] counting sort: scatter to cell-contiguous order (replaces the linked list of :104-124) */
-    SPH_K_BUILD_LIST     = 4,  /* [R] find_neighbors :126-153 once per rebuild: per-particle neighbour lists */
-    SPH_K_DENSITY_EOS    = 5,  /* :263-289 + :294-301                            */
-    SPH_K_FORCE_KICK     = 6,  /* :303-373 + :637-640                            */
-    SPH_K_HALO           = 7,  /* end-of-step marker (slab mode: halo pack/ingest) */
-    SPH_K_COUNT          = 8
-};
-typedef struct sph_kernel_times {
-    float ms[SPH_K_COUNT];     /* mean device time per step of each kernel, HIP events on the context's stream */
-    float step_ms;             /* mean device time of one whole step */
-    int   nsteps;
-    int   rebuilds;            /* how many of the nsteps rebuilt the neighbour structure */
-} sph_kernel_times;
-
 /* reference defaults (:11-20), box 4 x 2 */
 void sph_params_default(sph_params *prm);
 int  sph_abi_version(void);
@@ -177,24 +155,9 @@ float sph_device_cell(const sph_params *prm);
 int   sph_request_rebuild(sph_ctx *ctx);
 /* rebuilds since creation, and tiles that list builds have put on the direct (no list) path */
 int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
-/* why list builds put tiles on the direct path so far, as counts: [0] the tile touches more column pairs than the build's
- * tables hold, [1] more rows between its first and last particle than its row bitmap, [2] more runs of rows or cell-table
- * entries, [3] more candidates than the LDS tile, [4] a candidate window longer than a list byte can index, [5] a
- * neighbour list longer than the list capacity; and [6] workgroups of one-launch rebuilds that did not run on the XCD of
- * their grid-barrier leader and took the slow path (measurement / diagnostics) */
-int   sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]);
 /* Verification of failing box pairs (k_verify; one more launch per step): mode -1 = automatic (from 500 000 particles on, where
  * a rebuild costs far more than a launch), 0 = never, 1 = always.  Single-GPU contexts with the one-launch rebuild and skin > 0. */
 int  sph_set_verification(sph_ctx *ctx, int mode);
-/* pairs of box groups whose particles were checked one by one (instead of a rebuild) because their boxes had moved more
- * than the skin relative to each other (single-GPU contexts; see k_check in csrc/sph_kernels.hip) */
-int  sph_verify_stats(sph_ctx *ctx, long long *pairs);
-/* who asked for the rebuilds so far (requests, several may ask for the same rebuild): why[0] box pairs that could not be verified
- * (too many failing neighbours of one group, the queue full, or a mode without verification), why[1] the verification found a
- * pair missing from the lists, why[2] a particle drifted H + skin from its sort position, why[3] rest mode: beyond skin/2 */
-int  sph_rebuild_reasons(sph_ctx *ctx, long long why[4]);
-/* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
-int   sph_check_stats(sph_ctx *ctx, long long *checks);
 /* total particles clamped into the domain so far (0 in a healthy run) */
 long long sph_out_of_domain_count(sph_ctx *ctx);
 
@@ -210,23 +173,11 @@ int  sph_eval_density(sph_ctx *ctx);                       /* calculate_density 
 int  sph_eval_pressure(sph_ctx *ctx);                      /* calculate_particle_pressure :294-301, from the stored rho */
 int  sph_eval_accel(sph_ctx *ctx, float gx, float gy);     /* calculate_accelerations :303-373, from the stored x,y,u,v,rho,p */
 
-/* ---- measurement ---- */
-/* run nsteps steps eagerly with HIP events around every kernel (same kernels as sph_step) */
-int  sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_times *out);
-/* mean device time [ms] of `reps` back-to-back launches of ONE per-step kernel on the live state, between two HIP
- * events on the context's stream.  Only the idempotent kernels (SPH_K_DENSITY_EOS, SPH_K_FORCE_KICK: same
- * inputs -> same outputs, nothing they read is overwritten) can be timed this way; others give SPH_E_ARG.
- * SPH_K_FORCE_KICK re-does the kick of the last step: valid only after at least one sph_step since creation / upload /
- * sph_eval_accel (SPH_E_STATE otherwise: the velocities would be kicked a second time).  SPH_K_BUILD_LIST (single-GPU
- * contexts) rebuilds the lists on the sort that is there and leaves the rebuild request raised, so the next step
- * redoes the whole neighbour structure. */
-int  sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms);
+/* ---- streams, memory, launch structure ---- */
 /* adopt an existing hipStream_t (e.g. the host framework's current stream); NULL = own stream */
 int  sph_set_stream(sph_ctx *ctx, void *hip_stream);
 /* device bytes held by the context */
 size_t sph_device_bytes(const sph_ctx *ctx);
-/* select kernel variant for density/force: 0 = default (best), others for A/B measurements */
-int  sph_set_variant(sph_ctx *ctx, int variant);
 /* How a step launches its rebuild chain (binning, scan, scatter, lists): one_launch = 1 (default of single-GPU contexts):
  * ONE kernel with grid barriers between the phases, sized to what the device holds at once, so that the many steps
  * that rebuild nothing pay for one empty launch instead of four.  It needs the device to itself: sph_create tries its

@@ -48,7 +48,10 @@ class Oracle:
     """The CPU restatement. kind = 'strict' (-O2, bit-exact gate) or 'fast' (reference flags, timing)."""
 
     def __init__(self, kind="strict"):
-        path = os.path.join(HERE, "liborc_%s.so" % kind)
+        san = os.environ.get("ORC_SANITIZE", "")      # "asan": the ASan + UBSan build (make -C oracle asan; tests/test_sanitizers.py)
+        path = os.path.join(HERE, "liborc_%s%s.so" % (kind, "_" + san if san else ""))
+        if san and not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", HERE, san])
         if not os.path.exists(path):
             build(fast=(kind == "fast"), strict=(kind == "strict"))
         self.lib = C.CDLL(path)

@@ -18,7 +18,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_HIP = os.path.join(HERE, "csrc", "libsph_hip.so")      # (measurement scripts may point this at an A/B build before first use)
-LIB_HOST = os.path.join(HERE, "host", "libsph_host.so")
+LIB_HOST = os.environ.get("SPH_HOST_LIB") or os.path.join(HERE, "host", "libsph_host.so")      # (SPH_HOST_LIB: the sanitizer build, tests/test_sanitizers.py)
 
 # byte-compatible with the reference's `struct particle` (pi_sph_fluid.c:26-31)
 PARTICLE = np.dtype([("x", "<f4"), ("y", "<f4"), ("u", "<f4"), ("v", "<f4"),
@@ -33,20 +33,24 @@ KERNEL_ALGO_BYTES = {"kick_drift": 40.0, "key_hist": 4.0 + 5.2, "reorder": 44.0,
 STEP_ALGO_BYTES = 152.0
 
 # every symbol include/sph.h and include/sph_host.h declare
-ABI_SYMBOLS = [
+ABI_SYMBOLS = [      # include/sph.h: the drop-in boundary (+ slabs, metaballs)
     "sph_params_default", "sph_abi_version", "sph_error_string", "sph_device_count",
     "sph_create", "sph_destroy", "sph_last_error", "sph_step", "sph_sync",
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_set_boundary_velocity", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
-    "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_get_rebuild_launches", "sph_rebuild_stats", "sph_check_stats",
-    "sph_direct_tile_reasons", "sph_current_skin", "sph_verify_stats", "sph_rebuild_reasons", "sph_set_verification",
+    "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_get_rebuild_launches", "sph_rebuild_stats",
+    "sph_current_skin", "sph_set_verification",
     "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
-    "sph_profile_steps", "sph_time_kernel", "sph_set_stream", "sph_device_bytes", "sph_set_variant",
+    "sph_set_stream", "sph_device_bytes",
     "sph_render_metaballs",
     "sph_create_slab", "sph_slab_step_begin", "sph_slab_step_pack", "sph_slab_step_overlap", "sph_slab_step_overlap_on", "sph_slab_step_end",
     "sph_slab_peer_reduce", "sph_slab_peer_push", "sph_slab_peer_wait",
     "sph_slab_flag_buffer", "sph_slab_set_flag_buffer", "sph_slab_flag_get", "sph_slab_flag_set", "sph_slab_buffers", "sph_slab_set_buffers",
     "sph_slab_copy_out", "sph_slab_copy_in", "sph_slab_read", "sph_slab_counts", "sph_slab_halo_bytes",
+]
+DIAG_SYMBOLS = [     # include/sph_diag.h: measurement and diagnostics (bench.py, profiling, tests)
+    "sph_profile_steps", "sph_time_kernel", "sph_set_variant",
+    "sph_direct_tile_reasons", "sph_verify_stats", "sph_rebuild_reasons", "sph_check_stats",
 ]
 HOST_SYMBOLS = [
     "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",

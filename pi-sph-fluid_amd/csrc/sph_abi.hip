@@ -14,6 +14,7 @@
 #include <atomic>
 
 #include "sph.h"
+#include "sph_diag.h"
 #include "sph_internal.h"
 
 using namespace sph;

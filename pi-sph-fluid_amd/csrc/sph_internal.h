@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "sph.h"
+#include "sph_diag.h"
 
 namespace sph {
 

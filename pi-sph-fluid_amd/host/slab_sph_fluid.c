@@ -68,7 +68,9 @@
 #include <unistd.h>
 
 #include "sph.h"
+#include "sph_diag.h"      /* sph_time_kernel, sph_rebuild_reasons: the figures the bench line reports */
 #include "sph_host.h"
+#include "sph_shm.h"
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, hipGetErrorString(e_)); return 1; } } while (0)
 #define NCCLCHK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, ncclGetErrorString(r_)); return 1; } } while (0)
@@ -94,85 +96,21 @@ typedef struct {
  * ---------------------------------------------------------------------------------------------------------------- */
 enum { TR_RCCL = 0, TR_HOST = 1, TR_PEER = 2 };      /* (host and peer: set-up and the small collectives through shared memory) */
 
-typedef struct shm_hdr {
-    pthread_barrier_t bar;
-    int nranks;
-    size_t halo_bytes, coll_bytes, coll_off, mail_off, total;
-} shm_hdr;
-
 typedef struct comm {
     int kind, rank, nranks;
     /* rccl */
     ncclComm_t nccl;
     void *d_coll;                 /* device staging of the small collectives */
-    /* host */
-    shm_hdr *shm;
-    char shm_name[160];
-    unsigned long seq;            /* collectives so far (parity: which of the two slots / mailboxes) */
-    unsigned long xseq;           /* all-to-all exchanges so far (names of their segments) */
+    /* host (and the set-up / small collectives of peer): the shared segment, sph_shm.h */
+    shm_comm sh;
     size_t coll_bytes, halo_bytes;
     int selfcomm;                 /* measurement (--selfcomm, one rank, rccl): the step's RCCL calls made anyway, to itself */
     int serial;                   /* --exchange-stream: 2 = serial (default), 0 = main, 1 = side */
 } comm;
 
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-static size_t shm_layout(shm_hdr *h, int nranks, size_t halo_bytes, size_t coll_bytes) {
-    h->nranks = nranks;
-    h->halo_bytes = align_up(halo_bytes, 64);
-    h->coll_bytes = align_up(coll_bytes, 64);
-    h->coll_off = align_up(sizeof(shm_hdr), 4096);
-    h->mail_off = align_up(h->coll_off + 2 * (size_t)nranks * h->coll_bytes, 4096);
-    h->total = h->mail_off + 2 * (size_t)nranks * 2 * h->halo_bytes;
-    return h->total;
-}
-static unsigned char *shm_coll(comm *cm, unsigned long parity, int r) {
-    return (unsigned char *)cm->shm + cm->shm->coll_off + ((size_t)(parity & 1ul) * (size_t)cm->nranks + (size_t)r) * cm->shm->coll_bytes;
-}
-static unsigned char *shm_mail(comm *cm, unsigned long parity, int r, int side) {
-    return (unsigned char *)cm->shm + cm->shm->mail_off + (((size_t)(parity & 1ul) * (size_t)cm->nranks + (size_t)r) * 2 + (size_t)side) * cm->shm->halo_bytes;
-}
-
-/* create (launcher, or the one in-process rank) or open (a rank) the shared segment */
-static int shm_create(const char *name, int nranks, size_t halo_bytes, size_t coll_bytes) {
-    shm_hdr tmp;
-    const size_t total = shm_layout(&tmp, nranks, halo_bytes, coll_bytes);
-    shm_unlink(name);
-    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0) { perror("shm_open"); return 1; }
-    if (ftruncate(fd, (off_t)total) != 0) { perror("ftruncate"); close(fd); shm_unlink(name); return 1; }
-    shm_hdr *h = (shm_hdr *)mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (h == MAP_FAILED) { perror("mmap"); shm_unlink(name); return 1; }
-    shm_layout(h, nranks, halo_bytes, coll_bytes);
-    pthread_barrierattr_t at;
-    pthread_barrierattr_init(&at);
-    pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
-    const int rc = pthread_barrier_init(&h->bar, &at, (unsigned)nranks);
-    pthread_barrierattr_destroy(&at);
-    munmap(h, total);
-    if (rc != 0) { fprintf(stderr, "pthread_barrier_init: %s\n", strerror(rc)); shm_unlink(name); return 1; }
-    return 0;
-}
-static int shm_attach(comm *cm, const char *name) {
-    const int fd = shm_open(name, O_RDWR, 0600);
-    if (fd < 0) { fprintf(stderr, "[rank %d] shm_open(%s): %s\n", cm->rank, name, strerror(errno)); return 1; }
-    struct stat sb;
-    if (fstat(fd, &sb) != 0 || sb.st_size < (off_t)sizeof(shm_hdr)) { close(fd); return 1; }
-    cm->shm = (shm_hdr *)mmap(NULL, (size_t)sb.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (cm->shm == MAP_FAILED) { cm->shm = NULL; return 1; }
-    if (cm->shm->nranks != cm->nranks || cm->shm->total != (size_t)sb.st_size) { fprintf(stderr, "[rank %d] shared segment %s does not match this run\n", cm->rank, name); return 1; }
-    snprintf(cm->shm_name, sizeof cm->shm_name, "%s", name);
-    return 0;
-}
-
 static int comm_barrier(comm *cm) {
     if (cm->nranks == 1) return 0;
-    if (cm->kind != TR_RCCL) {
-        const int rc = pthread_barrier_wait(&cm->shm->bar);
-        return rc != 0 && rc != PTHREAD_BARRIER_SERIAL_THREAD;
-    }
+    if (cm->kind != TR_RCCL) return shm_barrier(&cm->sh);
     int one = 1;      /* (a 4-byte all-reduce: RCCL has no barrier call) */
     HIPCHK(hipMemcpy(cm->d_coll, &one, sizeof one, hipMemcpyHostToDevice));
     NCCLCHK(ncclAllReduce(cm->d_coll, cm->d_coll, 1, ncclInt32, ncclSum, cm->nccl, NULL));
@@ -192,20 +130,7 @@ static int comm_allreduce(comm *cm, void *buf, size_t count, int op) {
         HIPCHK(hipMemcpy(buf, cm->d_coll, bytes, hipMemcpyDeviceToHost));
         return 0;
     }
-    const unsigned long par = cm->seq++;
-    memcpy(shm_coll(cm, par, cm->rank), buf, bytes);
-    CHK(comm_barrier(cm));      /* (the slot of this parity is written again two collectives later: a barrier lies in between) */
-    for (int r = 0; r < cm->nranks; r++) {
-        if (r == cm->rank) continue;
-        if (op == 0) {
-            const long long *o = (const long long *)shm_coll(cm, par, r);
-            for (size_t k = 0; k < count; k++) ((long long *)buf)[k] += o[k];
-        } else {
-            const float *o = (const float *)shm_coll(cm, par, r);
-            for (size_t k = 0; k < count; k++) if (o[k] > ((float *)buf)[k]) ((float *)buf)[k] = o[k];
-        }
-    }
-    return 0;
+    return shm_allreduce(&cm->sh, buf, count, op);
 }
 
 /* the rebuild word of this step, MAX-reduced over the ranks, on the context's stream */
@@ -230,6 +155,11 @@ typedef struct xchg {      /* what the exchange of a step needs besides the comm
     hipStream_t st, xst;
     hipEvent_t packed, arrived;
 } xchg;
+
+/* the callbacks of shm_exchange (sph_shm.h): the halo buffers of the context to and from the mailboxes */
+static int mail_out(void *ctx, int side, void *dst) { SPHCHK((sph_ctx *)ctx, sph_slab_copy_out((sph_ctx *)ctx, side, dst)); return 0; }
+static int mail_in(void *ctx, int side, const void *src) { SPHCHK((sph_ctx *)ctx, sph_slab_copy_in((sph_ctx *)ctx, side, src)); return 0; }
+static int mail_between(void *ctx) { SPHCHK((sph_ctx *)ctx, sph_slab_step_overlap((sph_ctx *)ctx)); return 0; }
 
 /* the halo exchange of this step with sph_slab_step_overlap beside it; on return the receive buffers are (rccl: will be,
  * in stream order) filled and sph_slab_step_end may follow */
@@ -270,14 +200,7 @@ static int comm_exchange(comm *cm, sph_ctx *ctx, const xchg *x) {
         HIPCHK(hipStreamWaitEvent(x->st, x->arrived, 0));
         return 0;
     }
-    const unsigned long par = cm->seq++;
-    if (x->has_left) SPHCHK(ctx, sph_slab_copy_out(ctx, 0, shm_mail(cm, par, cm->rank, 0)));
-    if (x->has_right) SPHCHK(ctx, sph_slab_copy_out(ctx, 1, shm_mail(cm, par, cm->rank, 1)));
-    SPHCHK(ctx, sph_slab_step_overlap(ctx));
-    CHK(comm_barrier(cm));
-    if (x->has_left) SPHCHK(ctx, sph_slab_copy_in(ctx, 0, shm_mail(cm, par, cm->rank - 1, 1)));       /* what the left neighbour sent right */
-    if (x->has_right) SPHCHK(ctx, sph_slab_copy_in(ctx, 1, shm_mail(cm, par, cm->rank + 1, 0)));
-    return 0;
+    return shm_exchange(&cm->sh, x->has_left, x->has_right, mail_out, mail_between, mail_in, ctx);
 }
 
 /* rccl: the exchange on the MAIN stream (the interior density pass runs on the side stream: step_once) */
@@ -349,11 +272,11 @@ static int comm_alltoallv(comm *cm, float *const *out, const long long *cnt, int
         if (d_s) (void)hipFree(d_s);
         if (d_r) (void)hipFree(d_r);
     } else if (n > 1) {      /* host: one shared segment per (source, destination) pair that carries anything */
-        const unsigned long seq = cm->xseq++;
+        const unsigned long seq = cm->sh.xseq++;
         char name[256];
         for (int q = 0; q < n && !rc; q++) {
             if (q == cm->rank || !cnt[q]) continue;
-            snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->shm_name, seq, cm->rank, q);
+            snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->sh.shm_name, seq, cm->rank, q);
             shm_unlink(name);
             const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
             const size_t bytes = rb * (size_t)cnt[q];
@@ -370,7 +293,7 @@ static int comm_alltoallv(comm *cm, float *const *out, const long long *cnt, int
             const long long b = mat[(size_t)s * n + cm->rank];
             if (s == cm->rank) memcpy((char *)dst + rb * (size_t)o, out[s], rb * (size_t)b);
             else if (b) {
-                snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->shm_name, seq, s, cm->rank);
+                snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->sh.shm_name, seq, s, cm->rank);
                 const int fd = shm_open(name, O_RDONLY, 0600);
                 const size_t bytes = rb * (size_t)b;
                 void *m = fd >= 0 ? mmap(NULL, bytes, PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;
@@ -384,7 +307,7 @@ static int comm_alltoallv(comm *cm, float *const *out, const long long *cnt, int
         if (comm_barrier(cm)) rc = 1;
         for (int q = 0; q < n; q++) {
             if (q == cm->rank || !cnt[q]) continue;
-            snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->shm_name, seq, cm->rank, q);
+            snprintf(name, sizeof name, "%s.x%lu.%d.%d", cm->sh.shm_name, seq, cm->rank, q);
             shm_unlink(name);
         }
     } else {
@@ -817,8 +740,8 @@ int main(int argc, char **argv) {
     rs.deterministic = deterministic;
     rs.capacity = capacity;
     rs.cm.kind = transport;
-    rs.cm.rank = rank;
-    rs.cm.nranks = nranks;
+    rs.cm.rank = rs.cm.sh.rank = rank;
+    rs.cm.nranks = rs.cm.sh.nranks = nranks;
     rs.cm.selfcomm = selfcomm;
     rs.cm.serial = xside;
     rs.cm.coll_bytes = coll_bytes;
@@ -872,7 +795,7 @@ int main(int argc, char **argv) {
         HIPCHK(hipMalloc(&rs.cm.d_coll, coll_bytes));
     } else if (nranks > 1) {
         if (!shm_name) { fprintf(stderr, "[rank %d] --transport host needs --shm (the launcher passes it)\n", rank); return 1; }
-        CHK(shm_attach(&rs.cm, shm_name));
+        CHK(shm_attach(&rs.cm.sh, shm_name));
     }
     if (transport == TR_PEER) CHK(peer_setup(&rs, halo_bytes));
     const double t_create = now_s();

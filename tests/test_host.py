@@ -17,6 +17,13 @@ def test_abi_library_loads_and_exports_every_declared_symbol(sph):
     assert declared == set(sph.ABI_SYMBOLS), declared ^ set(sph.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
+    # measurement / diagnostic entry points live in a header of their own (not part of the drop-in boundary)
+    diag = open(os.path.join(ROOT, "include", "sph_diag.h")).read()
+    ddecl = set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", diag))
+    assert ddecl == set(sph.DIAG_SYMBOLS), ddecl ^ set(sph.DIAG_SYMBOLS)
+    assert not (ddecl & declared)
+    for name in ddecl:
+        assert hasattr(L, name), name
     H = C.CDLL(sph.LIB_HOST)
     hheader = open(os.path.join(ROOT, "include", "sph_host.h")).read()
     hdecl = set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", hheader))
