@@ -200,9 +200,10 @@ name, threads, nsteps, windows = {name!r}, {threads}, {nsteps}, {windows}
 O = orc.Oracle("fast")
 prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
 p = O.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
-of, ob = f.view(orc.PARTICLE).copy(), b.view(orc.PARTICLE).copy()
+of, ob = O.first_touch(f.view(orc.PARTICLE), threads), b.view(orc.PARTICLE).copy()      # pages touched by the threads that work on them
 O.psi(p, ob)
 du, dv = O.eval(p, of, ob, 0.0, -9.81, threads=threads)
+du, dv = O.first_touch(du, threads), O.first_touch(dv, threads)
 O.steps(p, of, ob, 0.0, -9.81, du, dv, 2, threads=threads)
 rates = []
 for w in range(windows):
@@ -228,15 +229,60 @@ def physical_cores():
     return cores, len(allowed)
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup of this process may use (cpu.max of cgroup v2, cfs_quota of v1; the smallest along the
+    path to the root), or None when nothing limits it.  A GPU box of the pool shows 128 cores to sched_getaffinity and gives
+    the container a share of them: threads beyond the quota are throttled, and spinning OpenMP waiters burn it."""
+    best = None
+    try:
+        lines = open("/proc/self/cgroup").read().split()
+    except OSError:
+        lines = []
+    paths = []
+    for ln in lines:
+        parts = ln.split(":", 2)
+        if len(parts) != 3:
+            continue
+        if parts[0] == "0" and parts[1] == "":                      # v2
+            paths.append(("/sys/fs/cgroup", parts[2], "cpu.max"))
+        elif "cpu" in parts[1].split(","):                            # v1
+            paths.append(("/sys/fs/cgroup/cpu", parts[2], None))
+    for root, rel, v2file in paths or [("/sys/fs/cgroup", "/", "cpu.max")]:
+        rel = rel.strip("/")
+        while True:
+            d = os.path.join(root, rel) if rel else root
+            try:
+                if v2file:
+                    q, per = open(os.path.join(d, v2file)).read().split()[:2]
+                    val = None if q == "max" else float(q) / float(per)
+                else:
+                    q = float(open(os.path.join(d, "cpu.cfs_quota_us")).read())
+                    per = float(open(os.path.join(d, "cpu.cfs_period_us")).read())
+                    val = None if q <= 0 else q / per
+                if val is not None:
+                    best = val if best is None else min(best, val)
+            except (OSError, ValueError):
+                pass
+            if not rel:
+                break
+            rel = os.path.dirname(rel)
+    return best
+
+
 def cpu_baseline(sph, name, nsteps=20, windows=3):
     """The oracle (CPU restatement of the reference, reference flags -Ofast -march=native -fopenmp) timed on this
     host's cores on the same scene: the 'port' baseline (the reference itself cannot run > 65 534 particles: unsigned
-    short indices, pi_sph_fluid.c:78-79).  Two legs, each in a fresh process so that OpenMP reads its binding:
-    (a) 4 threads, the reference's shipped setting (:610); (b) one thread per physical core this process may use,
-    OMP_PROC_BIND=close OMP_PLACES=cores.  Median of `windows` windows of `nsteps` steps each; the better leg is the
-    baseline."""
+    short indices, pi_sph_fluid.c:78-79).  A thread sweep, each leg in a fresh process so that OpenMP reads its settings:
+    (a) 4 threads, the reference's shipped setting (:610); (b) as many threads as the container's CPU quota allows
+    (cpu_quota; skipped when there is none or it equals another leg); (c) one thread per physical core this process may
+    run on.  Legs up to the quota bind their threads (OMP_PROC_BIND=close OMP_PLACES=cores); legs beyond it wait passively
+    (OMP_WAIT_POLICY=passive: a spinning waiter in the serial `omp single` parts :612-627 would burn the quota the working
+    thread needs).  The particle arrays are first touched by the threads that work on them.  Median of `windows` windows of
+    `nsteps` steps each; the best leg is the baseline, all are reported."""
     subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liborc_fast.so"])   # -march=native of THIS host
     cores, logical = physical_cores()
+    quota = cpu_quota()
+    eff = len(cores) if quota is None else max(1, min(len(cores), int(quota + 0.5)))      # cores' worth of time there really is
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -245,9 +291,15 @@ def cpu_baseline(sph, name, nsteps=20, windows=3):
                 break
     except OSError:
         pass
+    plan = [("4 threads (reference setting :610)", min(4, len(cores)))]
+    if eff not in (plan[0][1], len(cores)):
+        plan.append(("%d threads = the container's CPU quota" % eff, eff))
+    if len(cores) != plan[0][1]:
+        plan.append(("all %d physical cores" % len(cores), len(cores)))
     legs = []
-    for label, threads, extra in (("4 threads (reference setting :610)", min(4, len(cores)), {}),
-                                  ("all physical cores, bound", len(cores), {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"})):
+    for label, threads in plan:
+        over = threads > eff
+        extra = {"OMP_WAIT_POLICY": "passive"} if over else {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"}
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), **extra)
         code = _CPU_LEG.format(root=ROOT, name=name, threads=threads, nsteps=nsteps, windows=windows)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=900)
@@ -257,17 +309,21 @@ def cpu_baseline(sph, name, nsteps=20, windows=3):
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
         rate = float(np.median(d["rates"]))
         n_fluid = d["n"]
-        legs.append({"label": label, "threads": threads, "timesteps_per_s": round(rate, 4),
-                     "value": round(rate * d["n"] / 1e6, 3), "windows": [round(x, 4) for x in d["rates"]]})
+        legs.append({"label": label + (", passive waiting (beyond the quota)" if over else ", bound to cores"), "threads": threads,
+                     "timesteps_per_s": round(rate, 4), "value": round(rate * d["n"] / 1e6, 3), "windows": [round(x, 4) for x in d["rates"]]})
         log("cpu_baseline:", legs[-1])
-    if not legs:          # (neither leg ran: the GPU result is still worth a line)
+    if not legs:          # (no leg ran: the GPU result is still worth a line)
         return None
     best = max(legs, key=lambda l: l["value"])
     res = {"value": best["value"], "unit": "Mparticle-steps/s", "timesteps_per_s": best["timesteps_per_s"],
-            "cores": best["threads"], "kind": "port", "legs": legs,
-            "sample": "median of %d windows of %d steps (after 2 warm-up) of the full %s scene, %d fluid particles; best of two "
-                      "legs (%s); host: %s, %d physical cores / %d logical CPUs available to this process"
-                      % (windows, nsteps, name, n_fluid, best["label"], model, len(cores), logical)}
+            "cores": min(best["threads"], eff), "threads": best["threads"], "kind": "port", "legs": legs,
+            "host": {"model": model, "physical_cores_visible": len(cores), "logical_cpus_visible": logical,
+                     "cgroup_cpu_quota": None if quota is None else round(quota, 2), "effective_cores": eff},
+            "sample": "median of %d windows of %d steps (after 2 warm-up) of the full %s scene, %d fluid particles; best of %d "
+                      "legs (%s); host: %s, %d physical cores / %d logical CPUs visible, cgroup CPU quota %s -> %d effective cores; "
+                      "`cores` = min(threads of the best leg, effective cores)"
+                      % (windows, nsteps, name, n_fluid, len(legs), best["label"], model, len(cores), logical,
+                         "none" if quota is None else "%.1f" % quota, eff)}
     try:          # the N > 1 runs of the same box quote it (they do not measure it again)
         with open(CPU_CACHE, "w") as fh:
             json.dump(dict(res, cached_from="the N = 1 run of bench.py on this host"), fh)

@@ -63,6 +63,8 @@ class Oracle:
         L.orc_scene_default.argtypes = [C.POINTER(OrcParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_first_touch_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int]
+        L.orc_first_touch_copy.restype = None
         L.orc_psi.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_int]
         L.orc_max_neighbors.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -130,6 +132,12 @@ class Oracle:
                                 _ptr(du), _ptr(dv), nsteps, threads or (os.cpu_count() or 1))
         if rc:
             raise RuntimeError("orc_steps rc=%d" % rc)
+
+    def first_touch(self, a, threads):
+        """a copy of `a` whose pages were first touched by the threads that will work on them (timing runs)"""
+        out = np.empty_like(a)
+        self.lib.orc_first_touch_copy(_ptr(out), _ptr(np.ascontiguousarray(a)), len(a), a.dtype.itemsize, threads)
+        return out
 
     def metaballs(self, p, fluid, threads=0):
         buf = np.zeros(1024, np.uint8)

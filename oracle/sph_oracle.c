@@ -431,6 +431,12 @@ int orc_scene_default(const orc_params *p, orc_particle **fluid_out, int *n_flui
 
 void orc_free(void *ptr) { free(ptr); }
 
+void orc_first_touch_copy(void *dst, const void *src, long n, int rec, int threads) {
+    if (threads < 1) threads = 1;
+    #pragma omp parallel for num_threads(threads) schedule(static)
+    for (long i = 0; i < n; i++) memcpy((char*)dst + (size_t)i * (size_t)rec, (const char*)src + (size_t)i * (size_t)rec, (size_t)rec);
+}
+
 /* ---- metaballs :380-411 with the pixel grid of :570-577 ---- */
 int orc_metaballs(const orc_params *p, unsigned char *draw_buffer, const orc_particle *fluid, int n_fluid, int threads) {
     consts k; make_consts(p, &k);

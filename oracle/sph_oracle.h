@@ -60,6 +60,10 @@ int  orc_steps(const orc_params *p, orc_particle *fluid, int n_fluid, const orc_
                float gx, float gy, float *du_dt, float *dv_dt, int nsteps, int threads);
 /* 128x64 1-bpp SSD1306 page-format bitmap (1024 bytes), pi_sph_fluid.c:380-411 + :570-577 */
 int  orc_metaballs(const orc_params *p, unsigned char *draw_buffer, const orc_particle *fluid, int n_fluid, int threads);
+/* timing aid (bench.py's cpu_baseline): copy `n` records of `rec` bytes with the static schedule of the physics loops, so that
+ * every page of a freshly allocated destination is first touched by the thread that will work on it (NUMA first touch; the
+ * reference gets the same from its own serial initialisation only by luck of the allocator: no counterpart) */
+void orc_first_touch_copy(void *dst, const void *src, long n, int rec, int threads);
 
 #ifdef __cplusplus
 }
