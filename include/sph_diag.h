@@ -62,7 +62,7 @@ int   sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]);
 int  sph_verify_stats(sph_ctx *ctx, long long *pairs);
 /* who asked for the rebuilds so far (requests, several may ask for the same rebuild): why[0] box pairs that could not be verified
  * (too many failing neighbours of one group, the queue full, or a mode without verification), why[1] the verification found a
- * pair missing from the lists, why[2] a particle drifted H + skin from its sort position, why[3] rest mode: beyond skin/2 */
+ * pair missing from the lists, why[2] a particle drifted H + skin from its sort position, why[3] unused (0) */
 int  sph_rebuild_reasons(sph_ctx *ctx, long long why[4]);
 /* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
 int   sph_check_stats(sph_ctx *ctx, long long *checks);

@@ -462,11 +462,12 @@ class Context:
         return a.value, b.value
 
     def set_verification(self, mode):
-        """True / False / None (automatic: from 500 000 particles on) — failing box pairs verified particle by particle (k_verify)."""
+        """True / None (default) / False — box groups whose displacement boxes have moved more than the skin relative to each other
+        are checked particle by particle by the density pass of the step (False: they ask for the rebuild at once)."""
         self._chk(self.L.sph_set_verification(self.h, -1 if mode is None else (1 if mode else 0)))
 
     def rebuild_reasons(self):
-        """(unverifiable box pairs, verification found a missing pair, drift cap, rest mode) — requests for a rebuild so far."""
+        """(unverifiable box pairs, verification found a missing pair, drift cap, unused) — requests for a rebuild so far."""
         a = (C.c_longlong * 4)()
         self._chk(self.L.sph_rebuild_reasons(self.h, a))
         return tuple(int(v) for v in a)

@@ -55,12 +55,9 @@ struct sph_ctx {
     bool velt_stale = false;     // the fused force pass does not store the velocity between steps: refresh_velt() before use
     bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
-    hipGraph_t graph[16] = {};         // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations); + 8: rest mode
-    hipGraphExec_t gexec[16] = {};
-    bool rest_mode = false;            // the step's graphs without a k_check launch (enqueue_step_body); decided in check_flags
-    int verify_mode = -1;              // k_check queues + k_verify: -1 = from VERIFY_MIN_PARTICLES on, 0 = never, 1 = always (sph_set_verification)
-    int rest_left = 0;                 // ... for this many more steps (REST_STEPS after a decision: a stale "at rest" costs little)
-    uint32_t mode_steps = 0, mode_checks = 0;      // the step / check counters at the last decision
+    hipGraph_t graph[8] = {};          // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations)
+    hipGraphExec_t gexec[8] = {};
+    int verify_mode = -1;              // the speculative density pass verifies failing box pairs particle by particle: 0 = never (they ask for the rebuild), else yes (sph_set_verification)
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
     bool one_launch_asked = false;  // sph_set_rebuild_launches(ctx, 1): the host vouches that nothing else computes on the device meanwhile
@@ -179,32 +176,35 @@ void refresh_velt(sph_ctx *ctx) {
     ctx->velt_stale = false;
 }
 
-// What a step launches after its kick/drift (SPH_K_* order; ev != nullptr records an event before each): the rebuild
-// kernels (no-ops unless requested), density + EOS, force + kick.  With the list kernels the force pass also
-// integrates the next step's kick 1/2 + drift (FORCE_KICK_DRIFT).
-constexpr int VERIFY_MIN_PARTICLES = 500000;      // k_check queues + k_verify from this many particles on
+// What a step launches after its kick/drift.
+//   The step of sph_step (single GPU, list kernels, the one-launch rebuild available): THREE kernels —
+//     density + EOS, speculative: it assumes the lists valid and evaluates the rebuild criterion of every box group on the way
+//       (check_inline / verify_inline in sph_list.inc: what k_check and k_verify do as launches of their own);
+//     k_rebuild: the gate — nothing to do in ~95 % of the steps; else binning, scan, scatter, lists AND the density pass again;
+//     force + kick + the next step's kick 1/2 + drift (FORCE_KICK_DRIFT), which leaves the displacement boxes for the next check.
+//   The legacy order (ev != nullptr: the profiled step, an event before each kernel in SPH_K_* order; contexts that may share
+//   their device; the direct variant): k_check [+ k_verify], the rebuild as one kernel per phase, density, force.
+bool speculative(const sph_ctx *ctx) { return !ctx->slab && fused(ctx) && ctx->rebuild_wgs > 0; }
 void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
-    if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
-    const bool rest = ctx->rest_mode && ctx->rebuild_wgs > 0 && !ev && !ctx->slab;      // (see check_flags)
-    // beyond skin/2: do neighbouring groups still move together?  (their failing pairs are verified by the one-launch rebuild)
-    // (the verification is a launch more per step, ~3 us: it pays where a rebuild is expensive, i.e. with many particles —
-    // 262 144 particles, cfg1: 43.5k -> 38k steps/s with it; 2 000 000, cfg2: +9 % in the protocol's median window)
-    const bool verify = !ctx->slab && !rest && ctx->rebuild_wgs > 0 && !ev && ctx->c.skin_max > 0.0f &&
-                        (ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0);
-    if (!ctx->slab && !rest) launch_check(st, ctx->c, ctx->a, ctx->cap, nullptr, verify);
-    if (verify) launch_verify(st, ctx->c, ctx->a);
-    if (ctx->rebuild_wgs > 0 && !ev) {
-        launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, rest);
-    } else {       // (the profiled step, and contexts that may share their device: one kernel per phase)
-        launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
-        if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
-        launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
-        if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
-        launch_reorder(st, ctx->c, ctx->a, ctx->cap, ctx->deterministic);
-        if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
-        launch_build_list(st, ctx->c, ctx->a, ctx->cap);
+    if (speculative(ctx) && !ev) {
+        launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_ALL, false, true, ctx->verify_mode != 0);
+        launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, true);
+        launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);
+        return;
     }
+    if (ev) (void)hipEventRecord(ev[SPH_K_KEY_HIST], st);
+    // beyond skin/2: do neighbouring groups still move together?  (boxes only: two that have moved more than the skin relative
+    // to each other ask for the rebuild)
+    if (!ctx->slab) launch_check(st, ctx->c, ctx->a, ctx->cap, nullptr);
+    // (one kernel per phase)
+    launch_key_only(st, ctx->c, ctx->a, ctx->cap, ctx->a.vel);
+    if (ev) (void)hipEventRecord(ev[SPH_K_SCAN], st);
+    launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
+    if (ev) (void)hipEventRecord(ev[SPH_K_REORDER], st);
+    launch_reorder(st, ctx->c, ctx->a, ctx->cap, ctx->deterministic);
+    if (ev) (void)hipEventRecord(ev[SPH_K_BUILD_LIST], st);
+    launch_build_list(st, ctx->c, ctx->a, ctx->cap);
     if (ev) (void)hipEventRecord(ev[SPH_K_DENSITY_EOS], st);
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, DENS_ALL, false);
     if (ev) (void)hipEventRecord(ev[SPH_K_FORCE_KICK], st);
@@ -213,7 +213,7 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
 }
 
 void drop_graph(sph_ctx *ctx) {
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < 8; k++) {
         if (ctx->gexec[k]) { (void)hipGraphExecDestroy(ctx->gexec[k]); ctx->gexec[k] = nullptr; }
         if (ctx->graph[k]) { (void)hipGraphDestroy(ctx->graph[k]); ctx->graph[k] = nullptr; }
     }
@@ -223,7 +223,7 @@ void drop_graph(sph_ctx *ctx) {
 // (launch-latency bound at small N; replay costs one submission)
 hipGraphExec_t step_graph(sph_ctx *ctx) {
     if (!ctx->use_graph) return nullptr;
-    const int k = (ctx->a.pos == ctx->pos_a ? 0 : 1) + (ctx->rest_mode ? 8 : 0);
+    const int k = ctx->a.pos == ctx->pos_a ? 0 : 1;
     if (ctx->gexec[k]) return ctx->gexec[k];
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
@@ -248,7 +248,7 @@ hipGraphExec_t step_graph(sph_ctx *ctx) {
 constexpr int MULTI_STEPS = 8;      // the largest; 4 and 2 serve the remainder of a call (20 steps = 8 + 8 + 4: three replays)
 hipGraphExec_t multi_graph(sph_ctx *ctx, int steps = MULTI_STEPS) {
     if (!ctx->use_graph || (steps != 8 && steps != 4 && steps != 2)) return nullptr;
-    const int k = (steps == 8 ? 6 : steps == 4 ? 4 : 2) + (ctx->a.pos == ctx->pos_a ? 0 : 1) + (ctx->rest_mode ? 8 : 0);
+    const int k = (steps == 8 ? 6 : steps == 4 ? 4 : 2) + (ctx->a.pos == ctx->pos_a ? 0 : 1);
     if (ctx->gexec[k]) return ctx->gexec[k];
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
@@ -271,13 +271,13 @@ hipGraphExec_t multi_graph(sph_ctx *ctx, int steps = MULTI_STEPS) {
     return ctx->gexec[k];
 }
 
-// Both step graphs for both orientations of the position / velocity sets, captured, instantiated and uploaded NOW (context
-// creation): the first sph_step calls of a host are often the ones it times, and instantiating a 32-kernel graph inside
-// them cost ~0.3 ms (a 20-step window measured 116 us per step where 1000 steps measure 94).
+// The step graphs for both orientations of the position / velocity sets, captured, instantiated and uploaded at context
+// creation: the first sph_step calls of a host are often the ones it times, and instantiating a 24-kernel graph inside
+// them cost ~0.3 ms.  Not for contexts that cannot use them as they are: slabs, the direct variant, and contexts that find
+// company on their device (their first sph_step falls back to one kernel per phase and drops the graphs).
 void prebuild_graphs(sph_ctx *ctx) {
-    if (ctx->slab || !ctx->use_graph || !fused(ctx)) return;
-    for (int o = 0; o < 4 && ctx->use_graph; o++) {      // both orientations, then both again in rest mode
-        if (o == 2) ctx->rest_mode = !ctx->rest_mode;
+    if (ctx->slab || !ctx->use_graph || !fused(ctx) || device_shared(ctx)) return;
+    for (int o = 0; o < 2 && ctx->use_graph; o++) {      // both orientations
         hipGraphExec_t g = step_graph(ctx);
         if (g) (void)hipGraphUpload(g, ctx->stream);
         for (int m = MULTI_STEPS; m >= 2; m >>= 1) {
@@ -287,7 +287,6 @@ void prebuild_graphs(sph_ctx *ctx) {
         std::swap(ctx->a.pos, ctx->a.pos2);
         std::swap(ctx->a.vel, ctx->a.vel2);
     }
-    ctx->rest_mode = !ctx->rest_mode;      // (back to what it was)
     (void)hipGetLastError();
 }
 
@@ -327,20 +326,10 @@ int resort_state(sph_ctx *ctx) {
     return SPH_OK;
 }
 
-constexpr int REST_STEPS = 64;      // steps in rest mode after a synchronisation that found the fluid at rest
 int check_flags(sph_ctx *ctx) {
     uint32_t h[FLAG_COUNT] = {0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    // Rest mode for the steps to come?  Yes if none of the (at least four) steps since the last decision had anybody beyond
-    // skin/2 (the relative check never ran): their graphs then hold no k_check launch and treat "beyond skin/2" as
-    // "rebuild" (k_rebuild).  No: the usual four kernels.  Decided wherever the host synchronises anyway.
-    if (!ctx->slab && h[FLAG_STEP] - ctx->mode_steps >= 4u) {
-        ctx->rest_left = h[FLAG_NCHECK] == ctx->mode_checks ? REST_STEPS : 0;
-        ctx->rest_mode = ctx->rest_left > 0;
-        ctx->mode_steps = h[FLAG_STEP];
-        ctx->mode_checks = h[FLAG_NCHECK];
-    }
     if (h[FLAG_BAR_TIMEOUT]) {
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_BAR_TIMEOUT, 0, sizeof(uint32_t), ctx->stream));
         ctx->rebuild_wgs = 0;
@@ -494,8 +483,6 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4); ALLOC(a.dyn, DYN_COUNT);
-    a.vq = nullptr;
-    if (!slab) { ALLOC(a.vq, 2 + 2 * (size_t)VQ_CAP); }
     ALLOC(a.gbar, (size_t)GBAR_WORDS * GBAR_STRIDE);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 1024);
     ALLOC(ctx->d_ids, n);
@@ -539,7 +526,6 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         const Consts &c = ctx->c;
         const float hdyn[DYN_COUNT] = {0.0f, 0.0f, 0.0f, c.skin_min, 0.0f, 0.0f};
         a.uref = ctx->slab ? nullptr : a.dyn + DYN_UREF_X;      // (slabs: the absolute criterion — their references would differ)
-        if (a.vq) HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (2 + 2 * (size_t)VQ_CAP), st));
         HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
     }
 
@@ -658,7 +644,6 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     int s = 0;
     while (s < nsteps) {
-        ctx->rest_mode = ctx->rest_left > 0;      // (which set of graphs: check_flags)
         if (fused(ctx) && ctx->primed && nsteps - s >= 2) {
             const int m = nsteps - s >= 8 ? 8 : nsteps - s >= 4 ? 4 : 2;
             hipGraphExec_t g = multi_graph(ctx, m);
@@ -667,16 +652,13 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
                 ctx->velt_stale = true;
                 ctx->p_stale = true;
                 s += m;
-                ctx->rest_left = ctx->rest_left > m ? ctx->rest_left - m : 0;
                 continue;
             }
         }
         int rc = run_step(ctx, nullptr);
         if (rc) return rc;
         s++;
-        ctx->rest_left = ctx->rest_left > 1 ? ctx->rest_left - 1 : 0;
     }
-    ctx->rest_mode = ctx->rest_left > 0;
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
@@ -842,7 +824,7 @@ int sph_set_verification(sph_ctx *ctx, int mode) {
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->verify_mode = mode;
-    drop_graph(ctx);      // (the captured steps hold or do not hold the k_verify launch)
+    drop_graph(ctx);      // (an argument of the captured density launches)
     return SPH_OK;
 }
 

@@ -99,7 +99,6 @@ struct Arrays {
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
-    uint32_t *vq;       // verification queue (k_check -> k_rebuild): [0] count, [2 + 2 e ..] = (group, failing neighbour group); nullptr: slabs
     float *uref;        // where the density pass leaves the reference displacement (dyn + DYN_UREF_X; nullptr: slab contexts)
     float *dyn;         // DYN_COUNT floats: the list cut-off and the rebuild thresholds that follow from the current skin
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
@@ -127,7 +126,7 @@ enum {
     FLAG_OFF_XCD = 19,      // workgroups of one-launch rebuilds so far that did not run on the XCD of their barrier leader
     FLAG_STEP = 20,         // steps so far (k_check counts them)
     FLAG_LAST_REBUILD = 21, // FLAG_STEP at the last rebuild
-    FLAG_NVERIFY = 23,      // pairs of box groups that k_check verified particle by particle instead of asking for a rebuild
+    FLAG_NVERIFY = 23,      // pairs of box groups that the density pass verified particle by particle instead of asking for a rebuild
     FLAG_PEER_DONE = 22,    // workgroups of k_peer_push that have finished (grows: the last one of a launch raises the flags)
     FLAG_BAR_EPOCH = 24,    // launches that used grid barriers so far (the barrier words only grow: 8 values per such launch)
     FLAG_WHY_REBUILD = 25,  // who asked for the rebuilds (4 counters of requests, not of rebuilds): 0 the box check could not be
@@ -168,7 +167,6 @@ constexpr int LIST_WORDS_PER_TILE = 12 * SPH_TILE_PARTICLES;   // LROWS4 x TP (s
 constexpr int XRANGE_WORDS = 260;                              // 4 RMAX + 1 prefix sums, 4 RMAX first particles (sph_list.inc)
 constexpr int STAB_ENTRIES_PER_TILE = 896;                     // staging-table entries per tile (sph_list.inc)
 constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle list padding points at (finite: no NaN)
-constexpr int VQ_CAP = 4096;    // pairs of groups the verification queue holds (more: rebuild)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record
 
@@ -189,8 +187,10 @@ void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on);
 // between the phases: `grid` workgroups, all resident at once (rebuild_grid).  A no-op unless the rebuild word is set.
 int rebuild_grid(int device, int cap);
 // selftest: only the barriers (sph_create checks that they complete on this device before it relies on them)
+// spec: the launch follows the speculative density pass of the step (launch_density(..., spec = true)): it counts the step,
+// clears the check word and, when the rebuild word is raised, rebuilds AND repeats the density pass on the new lists
 void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool selftest = false, bool deterministic = false,
-                    bool rest_mode = false);
+                    bool spec = false);
 // slab mode, what follows the halo exchange, as one launch: ghost update, or (rebuild step) ingest -> scan -> scatter ->
 // canonical order of the interface cells -> tile records + lists
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag);
@@ -216,8 +216,7 @@ void launch_export_owned(hipStream_t st, const Consts &c, const Arrays &a, int c
 // single GPU: if the check word is set, compare the displacement boxes of neighbouring waves; raise the rebuild word
 // when two of them moved more than the skin relative to each other
 // gravity != nullptr: (gx, gy) of this step, written to the device by the same launch (slab step)
-void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity = nullptr, bool verify = false);
-void launch_verify(hipStream_t st, const Consts &c, const Arrays &a);
+void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity = nullptr);
 // rebuild kernels (no-ops unless flags[FLAG_REBUILD]): scan, scatter, tile records + neighbour lists
 void launch_scan(hipStream_t st, const Consts &c, uint32_t *count, uint32_t *dirty, uint32_t *cell_start,
                  uint32_t *block_sums, const uint32_t *rebuild, bool reduce);
@@ -234,8 +233,12 @@ enum { DENS_RHO = 0, DENS_RHO_EOS = 1 };
 enum { DENS_ALL = 0, DENS_INTERIOR = 1, DENS_REST = 2 };
 // store_p = false (the passes of a step): p itself is not written (4 bytes per particle that only a read-back looks at;
 // p / rho^2 is); the caller marks it stale and launch_eos restores it from rho, with the same arithmetic, on demand.
+// spec = true (single-GPU step, list kernels): the pass runs BEFORE the gate of the rebuild, assumes the lists valid and
+// evaluates the rebuild criterion of every box group on the way (what k_check + k_verify do as launches of their own); it
+// raises the rebuild word and clears nothing: launch_rebuild(..., spec = true) must follow.  verify (spec only): two boxes that
+// have moved more than the skin relative to each other are checked particle by particle; false: they ask for the rebuild.
 void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild,
-                    int pass = DENS_ALL, bool store_p = true);
+                    int pass = DENS_ALL, bool store_p = true, bool spec = false, bool verify = true);
 // what the force pass writes besides a: nothing / velt (second half kick) / velt + the next step's kick 1/2 + drift
 // into pos2, vel2 + the next step's rebuild request
 enum { FORCE_EVAL = 0, FORCE_KICK = 1, FORCE_KICK_DRIFT = 2 };

@@ -346,53 +346,17 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
 // the pair part of criterion (1): every box group against every group k_build_list listed for it, eight threads per group
 // (one per range of groups, two idle: the loads of a group are a chain of dependent latencies when one thread does them all)
 constexpr int CHECK_LANES = 8;
-// Verification (round 3, single-GPU contexts).  When the boxes of two groups have moved more than the skin relative to each
-// other, that is a bound, not a fact: the first pair that is really missing from a list comes 2 - 3 x later (measured on the
-// dam break).  So k_check does not ask for the rebuild: it QUEUES the failing pairs of groups (vq), and the next kernel,
-// k_verify, checks them particle by particle before the gate of k_rebuild, one wave per pair on a grid of its own (the pairs
-// are many — ~1000 per step late in a list's life — but 64 x 64 particle pairs each are nothing spread over the machine; by
-// the waves of k_check that found them they took longer than the rebuilds they saved).  A pair (p, q) is in the lists exactly
-// if it was within the list cut-off at the rebuild positions (the rule of the list build, on the same numbers: pos_ref); the
-// lists are stale only if a pair that is NOT has come inside the support.  The same groups fail their boxes again in the
-// following steps and are verified again, until a pair is really missing, or the queue overflows, or a lane has more failing
-// neighbours than it can remember: then the rebuild is asked for as before.
-#ifndef SPH_VERIFY_MAX
-#define SPH_VERIFY_MAX 8
-#endif
-constexpr int VERIFY_MAX = SPH_VERIFY_MAX;
+// (This kernel serves the steps that launch one kernel per phase: slab contexts, the profiled step, contexts that share their
+// device.  The step of sph_step evaluates the same criterion inside its density pass, and there two boxes that fail are not
+// the last word: their particles are checked one by one — check_inline / verify_inline, sph_list.inc.)
 DEV bool check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
-                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn,
-                     const bool verify, uint32_t (&fail_h)[VERIFY_MAX], int &nfail);
-// is a pair (p in group w, q in group h) that is in nobody's list inside the support now?  (one wave; wave-uniform answer)
-DEV bool verify_groups(const Consts &c, const int w, const int h, const int n, const uint2 *__restrict__ lrec,
-                       const float2 *__restrict__ pos, const float2 *__restrict__ pos_ref, const float cut_list2) {
-    const int lane = threadIdx.x & 63, pr = w * 64 + lane, qr = h * 64 + lane;
-    const bool vp = pr < n, vq = qr < n;
-    const int ip = vp ? (int)lrec[pr].x : 0, iq = vq ? (int)lrec[qr].x : 0;
-    const float2 xp = pos[ip], rp = pos_ref[ip], xq = pos[iq], rq = pos_ref[iq];
-    // (both thresholds on the safe side of the rounding: "not listed" a little early, "inside the support" a little early)
-    const float not_listed = cut_list2 * 0.999999f, inside = c.cut2 * 1.000001f;
-    bool hit = false;
-    const int iqv = vq ? iq : -1;
-    // (the q's by v_readlane with constant lanes — scalar operands of the compares; as ds_bpermute shuffles this loop was 8 us)
-#pragma unroll
-    for (int j = 0; j < 64; j++) {
-        const float qx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(xq.x), j));
-        const float qy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(xq.y), j));
-        const float sx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rq.x), j));
-        const float sy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rq.y), j));
-        const int qi = __builtin_amdgcn_readlane(iqv, j);
-        const float ex = rp.x - sx, ey = rp.y - sy, dx = xp.x - qx, dy = xp.y - qy;
-        hit |= qi >= 0 && qi != ip && fmaf(ex, ex, ey * ey) >= not_listed && fmaf(dx, dx, dy * dy) < inside;
-    }
-    return __any(hit && vp) != 0;
-}
+                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn);
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                                                const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
                                                uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
                                                const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
                                                uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy,
-                                               const float *__restrict__ dyn, uint32_t *__restrict__ vq) {
+                                               const float *__restrict__ dyn) {
     // the first kernel of every step: it counts them (the skin controller measures how many steps a set of lists lasted)
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_STEP], 1u);
     // (slab mode: the gravity of this step rides along instead of taking a launch of its own)
@@ -414,38 +378,17 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
         own_hi = (int)cs_ext(cs, (c.ghost + c.owned + (c.owned & 1)) * c.rows, c.n_cells);
         own_safe = (int)cs[(c.ghost + c.owned - (c.owned & 1)) * c.rows];
     }
-    // (skin 0 keeps its meaning — a rebuild in every step that moves anybody, like the reference's :626 — and with it the
-    // property that one GPU and any number of slabs rebuild in the same steps)
-#ifdef SPH_NO_VERIFY      // (A/B builds: make variant)
-    const bool verify = false;
-#else
-    const bool verify = vq != nullptr && BOXG == 64 && c.skin_max > 0.0f;
-#endif
     // (a small grid striding over the groups: see k_key_hist)
     for (int t = blockIdx.x * BLK + threadIdx.x; t < nw * CHECK_LANES; t += gridDim.x * BLK) {
-        uint32_t fail_h[VERIFY_MAX] = {};
-        int nfail = 0;
-        bool hard = check_group(c, wbox, wnbr, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi, own_safe, dyn, verify, fail_h, nfail);
-        if (nfail > 0 && !hard) {      // queue (this group, failing neighbour) for k_rebuild's verification
-            const uint32_t at = atomicAdd(&vq[0], (uint32_t)nfail);
-            if (at + (uint32_t)nfail <= (uint32_t)VQ_CAP) {
-#pragma unroll
-                for (int i = 0; i < VERIFY_MAX; i++)
-                    if (i < nfail) reinterpret_cast<uint2 *>(vq + 2)[at + (uint32_t)i] = make_uint2((uint32_t)(t / CHECK_LANES), fail_h[i]);
-            } else {
-                hard = true;      // the queue is full: the rebuild it is
-            }
-        }
-        if (hard) {
+        if (check_group(c, wbox, wnbr, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi, own_safe, dyn)) {
             atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);      // (never lowers a host's request)
             atomicAdd(&flags[FLAG_WHY_REBUILD + 0], 1u);
         }
     }
 }
-// returns true: rebuild (no verification possible or allowed); false: fine, or up to VERIFY_MAX failing neighbour groups in fail_h
+// returns true: the boxes of group w and of a group in its range k have moved more than the skin relative to each other -> rebuild
 DEV bool check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
-                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn,
-                     const bool verify, uint32_t (&fail_h)[VERIFY_MAX], int &nfail) {
+                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn) {
     const float skin2 = dyn[DYN_SKIN2];
     if (w * BOXG >= own_hi || (w + 1) * BOXG <= own_lo) return false;      // no owned particle in this group
     const float4 b = wbox[w];
@@ -474,52 +417,18 @@ DEV bool check_group(const Consts &c, const float4 *__restrict__ wbox, const uin
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float rx = fmaxf(b.z - q[j].x, q[j].z - b.x), ry = fmaxf(b.w - q[j].y, q[j].w - b.y);
-                const bool f = o + (uint32_t)j <= last && !(fmaf(rx, rx, ry * ry) <= skin2);
-                if (f && verify && nfail < VERIFY_MAX) {
-#pragma unroll
-                    for (int i = 0; i < VERIFY_MAX; i++)
-                        if (i == nfail) fail_h[i] = o + (uint32_t)j;      // (a register array: no dynamic index)
-                    nfail++;
-                } else {
-                    bad |= f;      // no verification, or a lane with more failing neighbours than it can remember
-                }
+                bad |= o + (uint32_t)j <= last && !(fmaf(rx, rx, ry * ry) <= skin2);
             }
         }
     }
     return bad;
 }
-// The pairs of groups k_check has queued, one wave per pair (a kernel of its own between k_check and the gate of k_rebuild:
-// as a phase of k_rebuild it needed a grid barrier for the verdict, ~11 us in four steps of five; a launch costs 3).
-__global__ __launch_bounds__(BLK) void k_verify(Consts c, const uint32_t *__restrict__ vq, uint32_t *__restrict__ rebuild,
-                                                uint32_t *__restrict__ flags, const uint32_t *__restrict__ dn,
-                                                const float *__restrict__ dyn, const uint2 *__restrict__ lrec,
-                                                const float2 *__restrict__ pos, const float2 *__restrict__ pos_ref) {
-    const uint32_t nverify = min(vq[0], (uint32_t)VQ_CAP);
-    if (nverify == 0u || *rebuild != 0u) return;      // (a rebuild somebody has asked for already makes the verification moot)
-    const int n = (int)dn[0];
-    const float cut_list2 = dyn[DYN_CUT_LIST2];
-    bool stale = false;
-    for (uint32_t e = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6); e < nverify; e += gridDim.x * (BLK / 64)) {
-        const uint2 pr = reinterpret_cast<const uint2 *>(vq + 2)[e];
-        stale |= verify_groups(c, (int)pr.x, (int)pr.y, n, lrec, pos, pos_ref, cut_list2);
-    }
-    if (stale && (threadIdx.x & 63u) == 0u) {
-        atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);
-        atomicAdd(&flags[FLAG_WHY_REBUILD + 1], 1u);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_NVERIFY], nverify);
-}
-void launch_verify(hipStream_t st, const Consts &c, const Arrays &a) {
-    if (!a.vq) return;
-    hipLaunchKernelGGL(k_verify, dim3(512), dim3(BLK), 0, st, c, a.vq, a.rebuild, a.flags, a.dn, a.dyn, a.lrec, a.pos, a.pos_ref);
-}
-// verify: k_verify follows and checks what this kernel queues (otherwise failing boxes ask for the rebuild)
-void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, bool verify) {
+void launch_check(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity) {
     if (cap <= 0) return;
     const int nw = (cap + BOXG - 1) / BOXG;
     hipLaunchKernelGGL(k_check, dim3(gated_grid((nw * CHECK_LANES + BLK - 1) / BLK)), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check,
                        a.rebuild, a.flags, a.dn, a.send[0], a.send[1], nw, gravity ? a.grav : nullptr, gravity ? gravity[0] : 0.0f,
-                       gravity ? gravity[1] : 0.0f, a.dyn, verify ? a.vq : nullptr);      // (a.vq: the verification queue of single-GPU contexts)
+                       gravity ? gravity[1] : 0.0f, a.dyn);
 }
 
 void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float2 *vsrc) {
@@ -1192,9 +1101,9 @@ void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const
 namespace sph {
 
 void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild,
-                    int pass, bool store_p) {
+                    int pass, bool store_p, bool spec, bool verify) {
     if (cap <= 0) return;
-    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild, pass, store_p); return; }
+    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild, pass, store_p, spec, verify); return; }
     if (pass == DENS_INTERIOR) return;      // the direct variant is not split: everything in the final pass
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
     uint32_t *rb = consume_rebuild ? a.rebuild : nullptr;

@@ -149,8 +149,9 @@ def test_fast_random_particles(sph, orc):
 
 
 def test_verification_instead_of_rebuilds(sph, orc):
-    """k_verify: the pairs of box groups whose boxes have moved more than the skin relative to each other are checked particle
-    by particle, and the lists are rebuilt only when a pair that is in nobody's list has come inside the support.  The same
+    """verify_inline (the density pass of the step): the pairs of box groups whose boxes have moved more than the skin relative
+    to each other are checked particle by particle, and the lists are rebuilt only when a pair that is in nobody's list has come
+    inside the support.  The same
     collapsing dam with and without it: the lists complete at every look (against the exact walk) in both; fewer rebuilds
     and some verified pairs with it; skin 0 keeps rebuilding every step (sph_set_verification has no effect there)."""
     res = {}
@@ -210,35 +211,39 @@ def test_skin_controller(sph, orc):
         assert direct == 0
 
 
-def test_rest_mode_steps_without_the_check_launch(sph, orc):
-    """After a synchronisation at which no step of the last interval needed the relative check, the step graphs hold no
-    k_check launch and k_rebuild treats "somebody beyond skin/2" as a rebuild request (sph_abi.hip, check_flags).  A tank
-    at rest stepped with such synchronisations equals the same tank stepped in one call (no rebuild in either: same bits);
-    a collapsing dam stepped with synchronisations stays exact (lists against the exact walk) and leaves rest mode again."""
-    prm, f, b = sph.scene_block((0.0, 30.6, 0.0, 8.0), 0.3, 0.3, 400, 60)
-    prm.deterministic = 1                   # (two contexts: the same bits only in the deterministic particle order)
-    with sph.Context(prm, f, b, GX, GY) as one:
-        one.step(120, GX, GY)
-        one.sync()
-        ref = one.read_particles()
-        r_one = one.rebuild_stats()[0]
-    with sph.Context(prm, f, b, GX, GY) as ctx:
-        for _ in range(12):
-            ctx.step(10, GX, GY)
-            ctx.sync()                      # (from the second chunk on: rest mode)
-        got = ctx.read_particles()
-        assert ctx.rebuild_stats()[0] == r_one and ctx.check_stats() == 0
-    for k in ("x", "y", "u", "v", "rho"):
-        assert np.array_equal(got[k], ref[k]), k
-    prm, f, b, g = block_scene(sph, orc, None)
-    with sph.Context(prm, f, b, GX, GY) as ctx:
-        done = 0
-        for k in (6, 12, 60, 200, 400):
-            ctx.step(k - done, GX, GY)
-            done = k
-            ctx.sync()
-            lists_vs_exact_walk(ctx, ("rest mode", k))
-        assert ctx.check_stats() > 0 and ctx.rebuild_stats()[1] == 0
+def test_host_synchronisation_points_do_not_change_the_run(sph, orc):
+    """The step of sph_step is three launches whatever the fluid does — density (which evaluates the rebuild criterion on the
+    way), the gate of the rebuild, force — decided on the device alone: where a host calls sph_sync has no influence on the
+    results or on the steps that rebuild (round 3 chose a cheaper set of graphs at synchronisation points).  A tank at rest and
+    a collapsing dam, each stepped in one call and in chunks with synchronisations: the same bits (deterministic particle
+    order), the same rebuilds; the dam's lists complete at the end (against the exact walk)."""
+    for scene in ("tank", "dam"):
+        if scene == "tank":
+            prm, f, b = sph.scene_block((0.0, 30.6, 0.0, 8.0), 0.3, 0.3, 400, 60)
+            total, chunk = 120, 10
+        else:
+            prm, f, b, g = block_scene(sph, orc, None)
+            total, chunk = 400, 25
+        prm.deterministic = 1                   # (two contexts: the same bits only in the deterministic particle order)
+        with sph.Context(prm, f, b, GX, GY) as one:
+            one.step(total, GX, GY)
+            one.sync()
+            ref = one.read_particles()
+            r_one, c_one = one.rebuild_stats()[0], one.check_stats()
+        with sph.Context(prm, f, b, GX, GY) as ctx:
+            for k in range(total // chunk):
+                ctx.step(chunk, GX, GY)
+                ctx.sync()
+            got = ctx.read_particles()
+            assert ctx.rebuild_stats()[0] == r_one and ctx.check_stats() == c_one, (scene, ctx.rebuild_stats(), r_one)
+            assert ctx.rebuild_stats()[1] == 0
+            if scene == "tank":
+                assert c_one == 0                # nobody beyond skin/2 in 120 steps of a tank at rest
+            else:
+                assert c_one > 0 and r_one >= 1
+                lists_vs_exact_walk(ctx, scene)      # (last: it re-evaluates rho and a in another summation order)
+        for k in ("x", "y", "u", "v", "rho"):
+            assert np.array_equal(got[k], ref[k]), (scene, k)
 
 
 def test_coherent_motion_keeps_lists(sph, orc, oracle):
@@ -324,7 +329,7 @@ def test_deterministic_runs_are_bit_identical(sph, orc):
     for one_launch in (True, True, False, False):
         with sph.Context(prm, f, b, GX, GY) as ctx:
             ctx.set_rebuild_launches(one_launch)
-            ctx.set_verification(True)      # (works with the one-launch rebuild only; this scene is below the automatic limit)
+            ctx.set_verification(True)      # (the default; the step with one kernel per phase — one_launch False — has no verification)
             a0 = ctx.read_accel()
             ctx.step(400, GX, GY)
             ctx.sync()
