@@ -72,6 +72,8 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
     prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
     if skin is not None:
         prm.skin = prm.skin_min = skin      # a fixed skin
+    elif os.environ.get("SPH_BENCH_SKIN_MIN"):      # (sweeps: the smallest skin of the adaptive range)
+        prm.skin_min = float(os.environ["SPH_BENCH_SKIN_MIN"])
     n = len(f)
     grav = sph.GravitySource(sph.GRAVITY_TILT, 9.81) if tilt else None
     dt_sim = float(np.float32(prm.dt))

@@ -471,13 +471,21 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
 #define ALLOC(ptr, cnt) if ((rc = dalloc(ctx, &(ptr), (cnt))) != SPH_OK) return rc
     ALLOC(a.pos, n); ALLOC(a.vel, n); ALLOC(a.pos2, n); ALLOC(a.vel2, n); ALLOC(a.id, n); ALLOC(a.rp, n); ALLOC(a.prs, n); ALLOC(a.acc, n);
     ALLOC(a.pk, n); ALLOC(a.velt, n); ALLOC(a.velk, n); ALLOC(a.skey, n); ALLOC(a.pos_ref, n);
-    const size_t ntiles = (n + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES + 9;
+    // (tile counts are padded to a multiple of 8 XCD_CHUNKS by the launchers: padded_grid, sph_list.inc)
+    const size_t ntiles = ((n + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES + 8 * XCD_CHUNKS - 1) / (8 * XCD_CHUNKS) * (8 * XCD_CHUNKS) + 9;
     ALLOC(a.tiles, TILE_WORDS * ntiles); ALLOC(a.nlist, (size_t)LIST_WORDS_PER_TILE * ntiles);
     ALLOC(a.lrec, ntiles * SPH_TILE_PARTICLES); ALLOC(a.stab, (size_t)STAB_ENTRIES_PER_TILE * ntiles);
     ALLOC(a.xranges, (size_t)XRANGE_WORDS * ntiles);
     ALLOC(a.tstart, 4 * (ntiles + 1)); ALLOC(a.pext, (size_t)ctx->c.cols + 4);
     const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / BOXG);      // box groups
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
+    a.vq = nullptr;
+    if (!slab) { ALLOC(a.vq, (size_t)VQ_SUB * VQ_WORDS); }
+    a.dcold = nullptr;
+    a.gver = nullptr;
+    a.wnl = nullptr;
+    if (!slab && BOXG == 64) { ALLOC(a.wnl, (size_t)64 * nwaves); }
+    if (!slab) { ALLOC(a.dcold, 1); ALLOC(a.gver, nwaves); }
     ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles * SCAN_SPREAD); ALLOC(a.bcell_start, pad); ALLOC(a.bnear, pad);
     ALLOC(a.dirty, tiles);
@@ -527,6 +535,13 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         const float hdyn[DYN_COUNT] = {0.0f, 0.0f, 0.0f, c.skin_min, 0.0f, 0.0f};
         a.uref = ctx->slab ? nullptr : a.dyn + DYN_UREF_X;      // (slabs: the absolute criterion — their references would differ)
         HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
+        if (a.vq) HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (size_t)VQ_SUB * VQ_WORDS, st));
+        if (a.gver) HIPCHK(ctx, hipMemsetAsync(a.gver, 0, sizeof(uint32_t) * (((size_t)ctx->cap + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES) * (SPH_TILE_PARTICLES / BOXG), st));
+        if (a.dcold) {
+            const DensCold hc = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.pos_ref, a.gver};
+            HIPCHK(ctx, hipMemcpyAsync(a.dcold, &hc, sizeof hc, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));      // (hc is a local)
+        }
     }
 
     // boundary: bin once, pseudo-mass once (:600-601)
@@ -841,10 +856,15 @@ int sph_rebuild_reasons(sph_ctx *ctx, long long why[4]) {
 int sph_verify_stats(sph_ctx *ctx, long long *pairs) {
     if (!ctx || !ctx->stream || !pairs) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
-    uint32_t h = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&h, ctx->a.flags + FLAG_NVERIFY, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *pairs = h;
+    long long sum = 0;
+    if (ctx->a.gver) {      // (the density pass keeps the statistic per box group: DensCold::gver)
+        const size_t ng = ((size_t)ctx->cap + BOXG - 1) / BOXG;
+        std::vector<uint32_t> h(ng);
+        HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->a.gver, sizeof(uint32_t) * ng, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t k = 0; k < ng; k++) sum += h[k];
+    }
+    *pairs = sum;
     return SPH_OK;
 }
 

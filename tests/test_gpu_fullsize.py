@@ -115,6 +115,6 @@ def test_fullsize_scene_vs_oracle(sph, orc, oracle, name, warm):
         ctx.upload_state(of)
         ctx.eval_accel(GX, GY)
         edu, edv = ctx.read_accel()
-        assert np.max(np.hypot(edu - sdu, edv - sdv) / (sa + G)) <= 2e-6
+        assert np.max(np.hypot(edu - sdu, edv - sdv) / (sa + G)) <= 4e-6      # (two summation orders of ~30 f32 terms)
     print("%s @%d: rebuilds %d, direct tiles %d (live) / %d (after re-bin), max speed %.1f m/s"
           % (name, warm, rebuilds, direct, direct2, float(np.hypot(got["u"], got["v"]).max())))
