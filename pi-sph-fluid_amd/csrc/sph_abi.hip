@@ -480,12 +480,10 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / BOXG);      // box groups
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     a.vq = nullptr;
-    if (!slab) { ALLOC(a.vq, (size_t)VQ_SUB * VQ_WORDS); }
-    a.dcold = nullptr;
-    a.gver = nullptr;
-    a.wnl = nullptr;
-    if (!slab && BOXG == 64) { ALLOC(a.wnl, (size_t)64 * nwaves); }
-    if (!slab) { ALLOC(a.dcold, 1); ALLOC(a.gver, nwaves); }
+    if (!slab) { ALLOC(a.vq, 2 + 2 * (size_t)VQ_CAP); }
+    a.djobs[0] = a.djobs[1] = nullptr;
+    a.pos_first = a.pos;
+    if (!slab) { ALLOC(a.djobs[0], 1); ALLOC(a.djobs[1], 1); }
     ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles * SCAN_SPREAD); ALLOC(a.bcell_start, pad); ALLOC(a.bnear, pad);
     ALLOC(a.dirty, tiles);
@@ -535,12 +533,14 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         const float hdyn[DYN_COUNT] = {0.0f, 0.0f, 0.0f, c.skin_min, 0.0f, 0.0f};
         a.uref = ctx->slab ? nullptr : a.dyn + DYN_UREF_X;      // (slabs: the absolute criterion — their references would differ)
         HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
-        if (a.vq) HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (size_t)VQ_SUB * VQ_WORDS, st));
-        if (a.gver) HIPCHK(ctx, hipMemsetAsync(a.gver, 0, sizeof(uint32_t) * (((size_t)ctx->cap + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES) * (SPH_TILE_PARTICLES / BOXG), st));
-        if (a.dcold) {
-            const DensCold hc = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.pos_ref, a.gver};
-            HIPCHK(ctx, hipMemcpyAsync(a.dcold, &hc, sizeof hc, hipMemcpyHostToDevice, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));      // (hc is a local)
+        if (a.vq) HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (2 + 2 * (size_t)VQ_CAP), st));
+        if (a.djobs[0]) {
+            const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, a.pos, a.pos_ref};
+            SpecJobs j1 = j0;
+            j1.pos = a.pos2;
+            HIPCHK(ctx, hipMemcpyAsync(a.djobs[0], &j0, sizeof j0, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(a.djobs[1], &j1, sizeof j1, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));      // (locals)
         }
     }
 
@@ -856,14 +856,10 @@ int sph_rebuild_reasons(sph_ctx *ctx, long long why[4]) {
 int sph_verify_stats(sph_ctx *ctx, long long *pairs) {
     if (!ctx || !ctx->stream || !pairs) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
-    long long sum = 0;
-    if (ctx->a.gver) {      // (the density pass keeps the statistic per box group: DensCold::gver)
-        const size_t ng = ((size_t)ctx->cap + BOXG - 1) / BOXG;
-        std::vector<uint32_t> h(ng);
-        HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->a.gver, sizeof(uint32_t) * ng, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t k = 0; k < ng; k++) sum += h[k];
-    }
+    uint32_t h = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h, ctx->a.flags + FLAG_NVERIFY, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const long long sum = h;
     *pairs = sum;
     return SPH_OK;
 }

@@ -51,16 +51,17 @@ struct Consts {
 };
 
 // Per-context device arrays. "S" = cell-sorted state, "T" = staging written by kick/drift.
-// What the epilogue of the speculative density pass needs (the rebuild criterion of a box group: sph_list.inc).  Kept in device
-// memory behind ONE kernel argument: as eight arguments these pointers were fetched at the top of the kernel and their sixteen
-// scalar registers lived across the whole walk — the pass then needed more than the 100 a wave may have at 8 waves per SIMD.
-struct DensCold {
+// What the rebuild-criterion jobs inside the launch of the speculative density pass need (spec_check_job, spec_verify_job:
+// sph_list.inc).  In device memory behind ONE kernel argument: as a dozen arguments of their own these pointers were fetched
+// at the top of the kernel by every workgroup and their scalar registers lived across the whole walk of the tiles' waves.
+struct SpecJobs {
     const float4 *wbox;
     const uint32_t *wnbr;
     const float *dyn;
     uint32_t *flags, *vq, *rebuild;
-    const float2 *pos_ref;
-    uint32_t *gver;      // per box group: how often it was counted / how many of its pairs were queued (the FLAG_NVERIFY statistic)
+    const uint32_t *check, *dn;
+    const uint2 *lrec;
+    const float2 *pos, *pos_ref;
 };
 
 struct Arrays {
@@ -106,15 +107,14 @@ struct Arrays {
     uint32_t *flags;    // see FLAG_*
     uint32_t *gbar;     // k_rebuild's grid barrier: GBAR_WORDS words, GBAR_STRIDE apart (arrivals, one per XCD, releases)
     float4 *wbox;       // per box group (BOXG consecutive lanes of a tile: a wave): bounding box of displacement since the last rebuild
-    uint32_t *wnl;      // per group (BOXG = 64): 64 words, the ranges of wnbr as a table — entry k = the k-th group of the sequence (single-GPU contexts)
     uint32_t *wnbr;     // per group: WNBR_WORDS words = 6 x {first, last} group whose particles may come near this group's
     uint32_t *latch;    // slab mode: copy of the reduced rebuild word of the current step (flags + FLAG_LATCH)
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
-    uint32_t *gver;     // DensCold::gver
-    DensCold *dcold;    // see DensCold (single-GPU contexts; filled once at creation: none of its members ever changes)
-    uint32_t *vq;       // verification queue (speculative density pass -> k_rebuild): VQ_SUB sub-queues of VQ_WORDS words; nullptr: slabs
+    SpecJobs *djobs[2]; // see SpecJobs (single-GPU contexts): [0] with pos = pos_first, [1] with the alternate set (filled once at creation)
+    float2 *pos_first;  // what pos pointed at when the context was created
+    uint32_t *vq;       // verification queue (spec_check_job -> spec_verify_job): [0] count, [2 + 2 e ..] = (group, failing neighbour group); nullptr: slabs
     float *uref;        // where the density pass leaves the reference displacement (dyn + DYN_UREF_X; nullptr: slab contexts)
     float *dyn;         // DYN_COUNT floats: the list cut-off and the rebuild thresholds that follow from the current skin
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
@@ -149,7 +149,7 @@ enum {
                             //   verified (a lane with too many failing neighbours, the queue full, no verification in this mode),
                             //   1 the verification found a pair missing from the lists, 2 somebody drifted H + skin from its sort
                             //   position (the cap), 3 rest mode: somebody beyond skin/2
-    FLAG_STALE = 29,        // k_rebuild's verification phase: the number of the last launch (FLAG_BAR_EPOCH + 1) that found a pair missing from the lists
+    FLAG_CHECK_DONE = 29,   // check jobs of the running density launch that have finished (spec_check_job; k_rebuild clears it)
     FLAG_COUNT = 30
 };
 // Arrays::dyn
@@ -188,10 +188,7 @@ constexpr int LIST_WORDS_PER_TILE = 12 * SPH_TILE_PARTICLES;   // LROWS4 x TP (s
 constexpr int XRANGE_WORDS = 260;                              // 4 RMAX + 1 prefix sums, 4 RMAX first particles (sph_list.inc)
 constexpr int STAB_ENTRIES_PER_TILE = 896;                     // staging-table entries per tile (sph_list.inc)
 constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle list padding points at (finite: no NaN)
-constexpr int VQ_SUB = 16;      // the verification queue as this many sub-queues (a wave takes the one of its group number: the counters are
-                                // hot words), each VQ_WORDS words: [0] count, [2 + 2 e ..] = (group, neighbour group beyond skin_max)
-constexpr int VQ_SUBCAP = 256;  // pairs per sub-queue (more: rebuild)
-constexpr int VQ_WORDS = 2 + 2 * VQ_SUBCAP;
+constexpr int VQ_CAP = 4096;    // pairs of groups the verification queue holds (more: rebuild)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record
 

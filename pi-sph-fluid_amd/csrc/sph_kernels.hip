@@ -347,10 +347,17 @@ __global__ __launch_bounds__(BLK) void k_key_hist(Consts c, const float2 *__rest
 // (one per range of groups, two idle: the loads of a group are a chain of dependent latencies when one thread does them all)
 constexpr int CHECK_LANES = 8;
 // (This kernel serves the steps that launch one kernel per phase: slab contexts, the profiled step, contexts that share their
-// device.  The step of sph_step evaluates the same criterion inside its density pass, and there two boxes that fail are not
-// the last word: their particles are checked one by one — check_inline / verify_inline, sph_list.inc.)
+// device.  The step of sph_step runs the same comparison as workgroups inside the launch of its density pass, and there two
+// boxes that fail are not the last word: their particles are checked one by one — spec_check_job / spec_verify_job, sph_list.inc.)
+// the failing neighbours a lane of the check remembers for the particle-by-particle verification (spec_check_job, sph_list.inc);
+// measured with 4 / 8 / 12: 8 404 / 8 790 / 8 793 steps/s in the protocol's median window
+#ifndef SPH_VERIFY_MAX
+#define SPH_VERIFY_MAX 8
+#endif
+constexpr int VERIFY_MAX = SPH_VERIFY_MAX;
 DEV bool check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
-                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn);
+                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn,
+                     const bool verify, uint32_t (&fail_h)[VERIFY_MAX], int &nfail);
 __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                                                const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
                                                uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
@@ -380,15 +387,20 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
     }
     // (a small grid striding over the groups: see k_key_hist)
     for (int t = blockIdx.x * BLK + threadIdx.x; t < nw * CHECK_LANES; t += gridDim.x * BLK) {
-        if (check_group(c, wbox, wnbr, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi, own_safe, dyn)) {
+        uint32_t fail_h[VERIFY_MAX] = {};
+        int nfail = 0;
+        if (check_group(c, wbox, wnbr, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi, own_safe, dyn, false, fail_h, nfail)) {
             atomicMax(rebuild, (uint32_t)REBUILD_CRITERION);      // (never lowers a host's request)
             atomicAdd(&flags[FLAG_WHY_REBUILD + 0], 1u);
         }
     }
 }
-// returns true: the boxes of group w and of a group in its range k have moved more than the skin relative to each other -> rebuild
+// The boxes of group w against those of the groups in its range k.  Returns true: rebuild (two boxes have moved more than the skin
+// relative to each other and there is no verification, or more of them than a lane remembers); false: fine, or up to VERIFY_MAX
+// failing neighbour groups in fail_h (verify: the caller has their particles checked one by one)
 DEV bool check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
-                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn) {
+                     const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn,
+                     const bool verify, uint32_t (&fail_h)[VERIFY_MAX], int &nfail) {
     const float skin2 = dyn[DYN_SKIN2];
     if (w * BOXG >= own_hi || (w + 1) * BOXG <= own_lo) return false;      // no owned particle in this group
     const float4 b = wbox[w];
@@ -417,7 +429,15 @@ DEV bool check_group(const Consts &c, const float4 *__restrict__ wbox, const uin
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float rx = fmaxf(b.z - q[j].x, q[j].z - b.x), ry = fmaxf(b.w - q[j].y, q[j].w - b.y);
-                bad |= o + (uint32_t)j <= last && !(fmaf(rx, rx, ry * ry) <= skin2);
+                const bool f = o + (uint32_t)j <= last && !(fmaf(rx, rx, ry * ry) <= skin2);
+                if (f && verify && nfail < VERIFY_MAX) {
+#pragma unroll
+                    for (int i = 0; i < VERIFY_MAX; i++)
+                        if (i == nfail) fail_h[i] = o + (uint32_t)j;      // (a register array: no dynamic index)
+                    nfail++;
+                } else {
+                    bad |= f;      // no verification, or a lane with more failing neighbours than it can remember
+                }
             }
         }
     }
