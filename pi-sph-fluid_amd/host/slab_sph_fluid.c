@@ -28,8 +28,8 @@
  *
  *   slab_sph_fluid --ranks N [--transport rccl|host|peer] [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--origin X0 Y0]
  *                  [--velocity U V] [--steps K] [--warmup W] [--tilt] [--check] [--deterministic] [--skin F]
- *                  [--rebalance-every K] [--capacity N] [--console] [--frame FILE] [--dump-state FILE] [--selfcomm]
- *                  [--exchange-stream serial|main|side]
+ *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE]
+ *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
  * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
  * what may sit under a profiler; the launcher must not: see profiles/README.md).  The ncclUniqueId travels through a file
@@ -45,6 +45,9 @@
  * serial 113-114, main 131-137, side 139-144 — a stream that is already waiting when the event it waits for fires resumes
  * ~13-15 us later, and the two overlapping orders pay that twice per step (fork and join), which is more than the ~15 us
  * send / receive kernel they hide; that kernel also takes twice as long (31 us) beside a density pass.
+ * --breakdown K: K more steps after the timed ones with HIP events at the phase boundaries, per rank (begin / reduction of the
+ * word / pack / exchange / end, us per step), printed per rank in the JSON line with its device, its particle counts and the
+ * ranks its communicator counts (ncclCommCount): one run tells an overloaded rank from a slow interconnect.
  * --selfcomm (N = 1, rccl; a measurement): the all-reduce and the grouped send / receive of every step are issued anyway,
  * to this rank itself: what the RCCL calls of a step cost (enqueue + their kernels) before any neighbour is waited for.
  */
@@ -407,7 +410,7 @@ static float max_abs_diff(const sph_particle *a, const sph_particle *b, const un
 typedef struct rank_state {
     sph_params prm;
     comm cm;
-    int device, transport, deterministic, capacity;
+    int device, transport, deterministic, capacity, halo_capacity;
     int own_device;              /* no other rank of this run on this rank's device (peer: as many devices as ranks) */
     sph_particle *walls;
     long nw;
@@ -422,6 +425,9 @@ typedef struct rank_state {
     void *peer_blk, *peer_of[SPH_PEER_MAX_RANKS];
     size_t peer_halo;            /* bytes per halo buffer inside a block */
     uint32_t peer_tag;
+    /* --breakdown: events around the parts of a step (serial rccl and peer: everything is on the one stream) */
+    hipEvent_t bev[6];
+    int bd_on;                   /* record them in this step */
 } rank_state;
 
 /* layout of a peer block: [send_l][send_r][recv_l][recv_r][flag from left | flag from right (256 B apart)][slots] */
@@ -494,7 +500,7 @@ static void peer_teardown(rank_state *rs) {
 
 /* a slab context for columns [c0, c1) from the particles given, wired to the rank's streams and transport */
 static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc, const unsigned *ids, long n_loc, float gx, float gy) {
-    sph_slab_desc desc = {c0, c1, rs->cm.rank > 0, rs->cm.rank < rs->cm.nranks - 1, 0, rs->capacity};
+    sph_slab_desc desc = {c0, c1, rs->cm.rank > 0, rs->cm.rank < rs->cm.nranks - 1, rs->halo_capacity, rs->capacity};
     rs->ctx = NULL;
     SPHCHK(rs->ctx, sph_create_slab(&rs->ctx, &rs->prm, &desc, loc, ids, (int)n_loc, rs->walls, (int)rs->nw, gx, gy, rs->device));
     SPHCHK(rs->ctx, sph_set_stream(rs->ctx, rs->st));
@@ -524,8 +530,11 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
 }
 
 /* one time step (:612-641) of this rank's slab */
+#define BD(k) do { if (rs->bd_on) HIPCHK(hipEventRecord(rs->bev[k], rs->st)); } while (0)
 static int step_once(rank_state *rs, float gx, float gy) {
+    BD(0);
     SPHCHK(rs->ctx, sph_slab_step_begin(rs->ctx, gx, gy));
+    BD(1);
     if (rs->cm.kind == TR_PEER) {
         /* everything between the ranks as stores into mapped peer memory and flag words, on the one stream */
         const int me = rs->cm.rank, n = rs->cm.nranks;
@@ -533,7 +542,9 @@ static int step_once(rank_state *rs, float gx, float gy) {
         void *slots[SPH_PEER_MAX_RANKS];
         for (int q = 0; q < n; q++) slots[q] = (char *)rs->peer_of[q] + peer_off_slots(rs);
         if (n > 1 || rs->cm.selfcomm) SPHCHK(rs->ctx, sph_slab_peer_reduce(rs->ctx, slots, me, n, tag));
+        BD(2);
         SPHCHK(rs->ctx, sph_slab_step_pack(rs->ctx));
+        BD(3);
         if (rs->cm.selfcomm && n == 1) {      /* (a measurement: the three kernels of the step against this rank's own block) */
             char *M = (char *)rs->peer_blk;
             SPHCHK(rs->ctx, sph_slab_peer_push(rs->ctx, M + peer_off_recv(rs, 1), M + peer_off_flag(rs, 1), M + peer_off_recv(rs, 0), M + peer_off_flag(rs, 0), tag));
@@ -547,15 +558,21 @@ static int step_once(rank_state *rs, float gx, float gy) {
             SPHCHK(rs->ctx, sph_slab_peer_wait(rs->ctx, rs->x.has_left ? M + peer_off_flag(rs, 0) : NULL,
                                                rs->x.has_right ? M + peer_off_flag(rs, 1) : NULL, tag));
         }
+        BD(4);
         SPHCHK(rs->ctx, sph_slab_step_end(rs->ctx));
+        BD(5);
         return 0;
     }
     if (rs->cm.kind == TR_RCCL && (rs->cm.nranks > 1 || rs->cm.selfcomm) && rs->cm.serial == 2) {
         /* everything on the main stream, nothing beside anything: no cross-stream event at all */
         CHK(comm_reduce_word(&rs->cm, rs->ctx, rs->flag, rs->st));
+        BD(2);
         SPHCHK(rs->ctx, sph_slab_step_pack(rs->ctx));
+        BD(3);
         CHK(comm_exchange_inline(&rs->cm, &rs->x));
+        BD(4);
         SPHCHK(rs->ctx, sph_slab_step_end(rs->ctx));
+        BD(5);
         return 0;
     }
     if (rs->cm.kind == TR_RCCL && (rs->cm.nranks > 1 || rs->cm.selfcomm) && !rs->cm.serial) {
@@ -575,11 +592,16 @@ static int step_once(rank_state *rs, float gx, float gy) {
         return 0;
     }
     CHK(comm_reduce_word(&rs->cm, rs->ctx, rs->flag, rs->st));
+    BD(2);
     SPHCHK(rs->ctx, sph_slab_step_pack(rs->ctx));
+    BD(3);
     CHK(comm_exchange(&rs->cm, rs->ctx, &rs->x));
+    BD(4);
     SPHCHK(rs->ctx, sph_slab_step_end(rs->ctx));
+    BD(5);
     return 0;
 }
+#undef BD
 
 /* Dynamic re-balancing: new column ranges at the quantiles of the CURRENT per-column particle histogram
  * (summed over the ranks), every particle shipped to the slab that now holds its column (owned + 2 ghost columns), the
@@ -658,7 +680,7 @@ static int rebalance(rank_state *rs, float gx, float gy, double min_gain, int *m
 
 int main(int argc, char **argv) {
     int nranks = 1, rank = -1, steps = 200, warmup = 50, tilt = 0, check = 0, deterministic = 0, transport = TR_RCCL;
-    int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2;
+    int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2, breakdown = 0, halo_capacity = -1;
     float skin = -1;
     const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL;
     scene_t sc = {0, 0, 0.3f, 0.3f, 0, 0, 0, 0, NULL};
@@ -679,6 +701,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--rebalance-every") && i + 1 < argc) rebalance_every = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--capacity") && i + 1 < argc) capacity = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--halo-capacity") && i + 1 < argc) halo_capacity = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--breakdown") && i + 1 < argc) breakdown = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frame") && i + 1 < argc) frame_file = argv[++i];
         else if (!strcmp(argv[i], "--dump-state") && i + 1 < argc) state_file = argv[++i];
         else if (!strcmp(argv[i], "--tilt")) tilt = 1;
@@ -712,7 +736,16 @@ int main(int argc, char **argv) {
     prm.x_max = sc.box_w;
     prm.y_max = sc.box_h;
     const int cols = sph_slab_grid_columns(&prm);
-    const size_t halo_bytes = sph_slab_halo_bytes(&prm, 0);
+    /* Records per halo buffer.  RCCL sends a whole buffer every step (the counts live on the device and ncclSend wants its size
+     * on the host), so the buffers are cut to the scene instead of the library's default (64 particles per row of cells): the two
+     * outermost columns of a lattice block ny high hold 2 ny cell / R particles at rest; 2.5 x that for what a collapse piles up
+     * (a rank that needs more ends in SPH_E_CAPACITY, not in wrong results).  --halo-capacity N sets it, 0 = the library's. */
+    if (halo_capacity < 0) {
+        const double per_col = (double)sc.ny * (double)sph_device_cell(&prm) / (double)prm.r;
+        long want = (long)(2.5 * 2.0 * per_col) + 1024, dflt = (long)(sph_slab_halo_bytes(&prm, 0) / (5 * sizeof(uint32_t)));
+        halo_capacity = (int)(want < dflt ? want : 0);
+    }
+    const size_t halo_bytes = sph_slab_halo_bytes(&prm, halo_capacity);
     size_t coll_bytes = sizeof(long long) * ((size_t)cols + (size_t)nranks * (size_t)nranks + 64);      /* histogram + counts ... */
     if (coll_bytes < 16384) coll_bytes = 16384;                                                          /* ... or the 1024 bytes of a frame as int64 */
 
@@ -739,6 +772,7 @@ int main(int argc, char **argv) {
     rs.transport = transport;
     rs.deterministic = deterministic;
     rs.capacity = capacity;
+    rs.halo_capacity = halo_capacity;
     rs.cm.kind = transport;
     rs.cm.rank = rs.cm.sh.rank = rank;
     rs.cm.nranks = rs.cm.sh.nranks = nranks;
@@ -894,6 +928,52 @@ int main(int argc, char **argv) {
     }
     long long rebuilds = 0, direct = 0;
     sph_rebuild_stats(rs.ctx, &rebuilds, &direct);
+    /* ---- --breakdown K: K more steps (outside the timed region) with an event at every phase boundary of the step, per rank:
+     * where a step's time goes — this rank's own kernels, or waiting for the others (the reduction of the word completes
+     * when the SLOWEST rank has contributed, the exchange when both neighbours have sent).  One line of diagnosis for a
+     * scaling curve: a rank with a long `begin`/`end` is overloaded (re-balance), long `reduce`/`exchange` everywhere is the
+     * interconnect or the collective.  Serial rccl and peer transports (everything on the one stream). ---- */
+    double bd[6] = {0, 0, 0, 0, 0, 0};      /* begin, reduce, pack, exchange, end (us per step), steps measured */
+    const int bd_ok = breakdown > 0 && ((transport == TR_RCCL && xside == 2) || transport == TR_PEER);
+    if (bd_ok) {
+        for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&rs.bev[k]));
+        CHK(comm_barrier(&rs.cm));
+        for (int s = 0; s < breakdown; s++) {
+            rs.bd_on = 1;
+            CHK(step_once(&rs, gx, gy));
+            rs.bd_on = 0;
+            HIPCHK(hipEventSynchronize(rs.bev[5]));
+            for (int k = 0; k < 5; k++) {
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, rs.bev[k], rs.bev[k + 1]));
+                bd[k] += 1e3 * (double)ms;
+            }
+            t += prm.dt;
+            sph_gravity_sample(&grav, t, &gx, &gy);
+        }
+        for (int k = 0; k < 5; k++) bd[k] /= (double)breakdown;
+        bd[5] = (double)breakdown;
+        rc = sph_sync(rs.ctx);
+        if (rc) { fprintf(stderr, "[rank %d] sph_sync after the breakdown steps: %d (%s)\n", rank, rc, sph_last_error(rs.ctx)); return 1; }
+    }
+    /* every rank's row {begin, reduce, pack, exchange, end, owned, local, device, ranks the communicator counts} -> rank 0 */
+    enum { BDW = 9 };
+    float *rows = (float *)calloc((size_t)nranks * BDW, sizeof(float));
+    if (!rows) return 1;
+    {
+        int seen = nranks;
+        if (transport == TR_RCCL) NCCLCHK(ncclCommCount(rs.cm.nccl, &seen));
+        float *mine = rows + (size_t)rank * BDW;
+        for (int k = 0; k < 5; k++) mine[k] = (float)bd[k];
+        mine[5] = (float)n_owned; mine[6] = (float)n_local; mine[7] = (float)rs.device; mine[8] = (float)seen;
+        /* (a sum over rows of which all but one are zero on every rank; floats: counts below 2^24 are exact) */
+        long long *tmp = (long long *)calloc((size_t)nranks * BDW, sizeof(long long));
+        if (!tmp) return 1;
+        for (int k = 0; k < nranks * BDW; k++) tmp[k] = (long long)llround((double)rows[k] * 16.0);
+        CHK(comm_allreduce(&rs.cm, tmp, (size_t)nranks * BDW, 0));
+        for (int k = 0; k < nranks * BDW; k++) rows[k] = (float)((double)tmp[k] / 16.0);
+        free(tmp);
+    }
     /* the two heavy kernels of this rank's slab, back to back on the live state (HIP events on the context's stream): what
      * bench.py prices against the HBM roofline */
     float dens_ms = 0, force_ms = 0;
@@ -907,10 +987,17 @@ int main(int argc, char **argv) {
         printf("{\"host\": \"slab_sph_fluid (C, %s)\", \"workload\": \"%s%s\", \"n_gpus\": %d, \"n_fluid\": %ld, \"n_boundary\": %ld, "
                "\"steps\": %d, \"warmup\": %d, \"ticks_per_s\": %.2f, \"mparticle_steps_per_s\": %.2f, \"ms_per_step\": %.5f, "
                "\"neighbour_rebuilds\": %lld, \"rebalanced\": %d, \"max_owned\": %lld, \"max_rho\": %.3f, \"max_speed\": %.3f, "
-               "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s}\n",
+               "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s, "
+               "\"halo_buffer_bytes\": %zu, \"breakdown_steps\": %d, \"per_rank\": [",
                transport == TR_RCCL ? "RCCL" : transport == TR_PEER ? "peer-mapped memory" : "host-staged shared memory", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
                steps, warmup, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
-               n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false");
+               n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false", rs.x.halo_bytes, bd_ok ? breakdown : 0);
+        for (int r = 0; r < nranks; r++) {
+            const float *q = rows + (size_t)r * BDW;
+            printf("%s{\"rank\": %d, \"device\": %d, \"ranks_seen\": %d, \"owned\": %.0f, \"local\": %.0f, \"begin_us\": %.1f, \"reduce_us\": %.1f, "
+                   "\"pack_us\": %.1f, \"exchange_us\": %.1f, \"end_us\": %.1f}", r ? ", " : "", r, (int)q[7], (int)q[8], q[5], q[6], q[0], q[1], q[2], q[3], q[4]);
+        }
+        printf("]}\n");
         fflush(stdout);
     }
     if (owned_total != (long long)n_total) { fprintf(stderr, "[rank %d] particles lost: %lld of %ld\n", rank, owned_total, n_total); return 1; }

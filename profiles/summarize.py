@@ -73,13 +73,18 @@ def main():
         lines.append("")
     # per-launch HBM traffic of the step kernels in bench.py's naming (read side doubled, see above)
     names = {"k_kick_drift<false>": "kick_drift", "k_key_hist<false>": "key_hist", "k_reorder": "reorder",
-             "k_build_list": "build_list", "k_density_list<1, 0>": "density_eos", "k_force_list<2, 0>": "force_kick", "k_check": "check",
+             "k_build_list": "build_list", "k_density_list<1, 0>": "density_eos", "k_density_list<1, 0, true>": "density_eos",
+             "k_density_list<1, 0, false>": "density_eos_plain", "k_force_list<2, 0>": "force_kick", "k_check": "check",
              "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply", "k_rebuild<0>": "rebuild"}
-    traffic = {}
+    traffic, valu = {}, {}
     for kn, bn in names.items():
         cs = merged.get(kn, {})
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             traffic[bn] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
+        if "SQ_INSTS_VALU" in cs:      # wave-instructions per launch (all SIMDs); the transcendental ones issue at a quarter of the rate
+            valu[bn] = {"insts": int(cs["SQ_INSTS_VALU"]), "trans": int(cs.get("SQ_INSTS_VALU_TRANS", 0))}
+    if valu:
+        traffic["_valu"] = valu
     if len(sys.argv) > 3 and traffic:
         import json
         path, workload = sys.argv[3], (sys.argv[4] if len(sys.argv) > 4 else "cfg2")

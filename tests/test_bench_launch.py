@@ -109,19 +109,45 @@ def test_c_host_two_ranks_over_peer_mapped_memory_through_bench(sph):
     assert out["n_gpus"] == 2 and out["particles_conserved"] is True and out["config"]["n_fluid"] == 4000000
     assert "hipIpc-mapped" in out["config"]["parallelism"] and "peer_transport" not in out
     sys.path.insert(0, ROOT)
-    import argparse
     import bench
-    leg = bench.peer_leg(os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid"), "dam", 2,
-                         argparse.Namespace(steps=30, warmup=10, workload="cfg2"))
-    assert leg["status"] == "ok" and leg["particles_conserved"] is True and leg["timesteps_per_s"] > 0 and "peer-mapped" in leg["host"], leg
-    # the default transport with more ranks than GPUs: the RCCL run refuses (one rank per GPU), bench.py falls back to the peer
-    # transport and says so
+    leg = bench.peer_leg(os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid"), "dam", 2, 30, 10, False)
+    assert leg["status"] == "ok" and leg["raw"]["particles_conserved"] is True and leg["raw"]["ticks_per_s"] > 0 and "peer-mapped" in leg["raw"]["host"], leg
+    # the default transport with more ranks than GPUs: the RCCL run refuses (one rank per GPU) and the bench FAILS — a transport
+    # that was asked for and did not run is not replaced silently ...
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "10"],
+                       capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode != 0 and b"RCCL does not share a device" in r.stderr
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    # ... unless the caller opts in: --transport auto falls back to the peer transport and says so
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "auto", "--steps", "30", "--warmup", "10"],
                        capture_output=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
-    assert out["n_gpus"] == 2 and out["particles_conserved"] is True and out["transport_used"].startswith("peer (the RCCL run")
-    assert b"RCCL does not share a device" in r.stderr
+    assert out["n_gpus"] == 2 and out["particles_conserved"] is True and out["transport_used"].startswith("peer (--transport auto")
+    assert out["transport"] == "peer"
     # a run that cannot start is reported, not raised
-    bad = bench.peer_leg(os.path.join(ROOT, "no_such_program"), "dam", 2, argparse.Namespace(steps=1, warmup=0, workload="cfg2"))
+    bad = bench.peer_leg(os.path.join(ROOT, "no_such_program"), "dam", 2, 1, 0, False)
     assert bad["status"].startswith("not started")
+
+
+@pytest.mark.gpu
+def test_six_ranks_rehearsal_weak_and_strong_legs(sph):
+    """The N > 1 line as the driver's 8-GPU node will get it, rehearsed on the one GPU of this box: `bench.py --gpus 6` over
+    the peer transport (six processes — the most this pool lets touch one GPU at a time; the multi-GPU node runs eight), the
+    weak-scaling run as the line's value and, under scaling_detail, the STRONG leg: cfg4 (32 000 000 particles under the tilt
+    trace) cut into the same six slabs, with the per-rank breakdown of a step (device, ranks seen, particles, begin / reduce /
+    pack / exchange / end) in both.  Small step counts: this is a rehearsal of the code path, not a measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--transport", "peer", "--steps", "12", "--warmup", "4"],
+                       capture_output=True, timeout=1100, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 6 and out["scaling"] == "weak" and out["particles_conserved"] is True and out["config"]["n_fluid"] == 12000000
+    pr = out["per_rank"]
+    assert len(pr) == 6 and [q["rank"] for q in pr] == list(range(6)) and all(q["ranks_seen"] == 6 for q in pr)
+    assert sum(q["owned"] for q in pr) == 12000000 and out["breakdown_steps"] > 0
+    assert all(q["begin_us"] > 0 and q["end_us"] > 0 and q["exchange_us"] > 0 for q in pr), pr
+    strong = out["scaling_detail"]["strong"]
+    assert strong["n_fluid"] == 32000000 and strong["particles_conserved"] is True and "tilt" in strong["workload"]
+    assert len(strong["per_rank"]) == 6 and sum(q["owned"] for q in strong["per_rank"]) == 32000000
+    assert out["scaling_detail"]["weak"]["n_fluid"] == 12000000
