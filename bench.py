@@ -741,6 +741,11 @@ def main():
         log("also:", json.dumps(r))
         out["also"].append(also_entry("cfg4 on one GPU: %d fluid + %d boundary, box 2400.6 x 150 m, scripted tilt gravity"
                                       % (r["n_fluid"], r["n_boundary"]), r, "cfg4"))
+        # ... and the same tank once the un-compressed lattice has fallen onto the floor (75 m of water: |v| to 60 m/s at the
+        # bounce): steps 2000 - 2600.  The HBM-resident DEVELOPED point: nothing fits the Infinity Cache and the lists are rebuilt
+        r = run_single(sph, "cfg4", 200, 2000, profile_steps=5, skin=args.skin, tilt=True, windows=3)
+        log("also:", json.dumps(r))
+        out["also"].append(also_entry("cfg4 on one GPU, developed flow: steps 2000-2600 of the same run", r, "cfg4_developed"))
     if out.get("also"):      # the N > 1 runs of this host quote these (weak efficiency, strong speed-up)
         try:
             ref = {"cfg2_window": out["timesteps_per_s"], "cfg2_window_steps": [args.warmup, args.steps]}

@@ -3,14 +3,23 @@ trace (the MPU6050 stand-in: 15 deg, 8 s, re-sampled every 0.1 s of simulated ti
 MI355X, twice: as a single context and as FOUR slab contexts (the decomposition the 8-GPU run uses, halo exchange through
 the host).  Gate G7 (N-GPU == 1-GPU): rho within 1e-5 while the two runs are comparable (300 steps); the un-compressed
 lattice then falls onto the floor (75 m of water: |v| reaches 60 m/s at the bounce), the flow turns chaotic and only
-aggregates and conservation are compared at step 2000."""
+aggregates and conservation are compared at step 2000 — and there ONE staged evaluation of the CPU oracle on slab 1's range
+of the developed state (its owned columns + two columns of halo, ~8 000 000 particles) under the gravity vector of that step: the
+slab's live rho (G1), p (G2) and the accelerations of its fused force pass (G3) within 1e-5, as tests/test_gpu_cfg3.py does for
+cfg3 (reference: get_gravity pi_sph_fluid.c:431-464, calculate_density / _particle_pressure / _accelerations :263-373)."""
+import os
+
 import numpy as np
 import pytest
 
+from conftest import B_EOS
+
 pytestmark = pytest.mark.gpu
+TOL = 1e-5
+THREADS = min(16, os.cpu_count() or 1)
 
 
-def test_cfg4_tilt_four_slabs_equal_single_context(sph):
+def test_cfg4_tilt_four_slabs_equal_single_context(sph, orc, oracle):
     spec = sph.BLOCK_SCENES["cfg4"]
     box, x0, y0, nx, ny = spec
     prm = sph.default_params(box)
@@ -63,7 +72,38 @@ def test_cfg4_tilt_four_slabs_equal_single_context(sph):
                     a, b = float(out[fld].astype(np.float64).mean()), float(ref[fld].astype(np.float64).mean())
                     assert abs(a - b) <= 1e-4 * abs(b), (fld, a, b)
                 assert slabs[0].rebuilds() == slabs[3].rebuilds() > 100        # all slabs rebuilt in the same steps
-            del ref, out, du, dv, seen
+            del ref, seen
+            if k == 300:
+                del out, du, dv
+    # ---- the oracle on slab 1's range of the developed state (step 2000): owned columns + 2 columns of halo on each side,
+    # under the gravity vector the last step was given ----
+    replay = sph.GravitySource(sph.GRAVITY_TILT, 9.81)      # (the source holds its value for 0.1 s since ITS last reading, like the
+    for j in range(2001):                                   # reference's polling thread :455-461: replay the readings of the run)
+        gx, gy = replay.sample(j * dt)
+    assert abs(gx) > 0.5                                                          # ~5.6 degrees of tilt by now
+    half_dt = 0.5 * dt
+    c0, c1 = parts[1]
+    gc = sph.slab.global_columns(prm, out["x"])
+    sel = np.nonzero((gc >= c0 - 2) & (gc < c1 + 2))[0]
+    own = (gc[sel] >= c0) & (gc[sel] < c1)
+    assert 6000000 < own.sum() < 10000000
+    assert np.hypot(out["u"][sel], out["v"][sel]).max() > 5.0                     # the lattice has fallen: a developed state
+    p = oracle.params(tuple(box))
+    ob = walls.view(orc.PARTICLE).copy()
+    oracle.psi(p, ob)
+    of = out[sel].view(orc.PARTICLE).copy()
+    oracle.eval(p, of, ob, gx, gy, flags=1, threads=THREADS)                                   # rho from x(t)
+    assert np.max(np.abs(out["rho"][sel][own] - of["rho"][own]) / of["rho"][own]) <= TOL      # G1 (through the slab's lists)
+    of["rho"] = out["rho"][sel]
+    oracle.eval(p, of, ob, gx, gy, flags=2, threads=THREADS)                                   # p from the GPU's rho
+    assert np.max(np.abs(out["p"][sel][own] - of["p"][own]) / (of["p"][own] + B_EOS)) <= TOL  # G2
+    # the force pass saw the half-kicked velocity (:328 reads u, v after :616): v_half = v - 0.5 DT a (:638)
+    of["p"] = out["p"][sel]
+    of["u"] = (out["u"][sel].astype(np.float64) - half_dt * du[sel].astype(np.float64)).astype(np.float32)
+    of["v"] = (out["v"][sel].astype(np.float64) - half_dt * dv[sel].astype(np.float64)).astype(np.float32)
+    odu, odv, sa = oracle.eval(p, of, ob, gx, gy, flags=4, threads=THREADS, want_sum_abs=True)
+    err = np.hypot(du[sel] - odu, dv[sel] - odv) / (sa + 9.81)
+    assert np.max(err[own]) <= TOL                                                            # G3 (fused force + kick pass)
     for s in slabs:
         s.close()
 
