@@ -155,8 +155,9 @@ float sph_device_cell(const sph_params *prm);
 int   sph_request_rebuild(sph_ctx *ctx);
 /* rebuilds since creation, and tiles that list builds have put on the direct (no list) path */
 int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
-/* Verification of failing box pairs by the density pass of sph_step: mode 0 = never (two boxes that have moved more than the skin
- * relative to each other ask for the rebuild), anything else (default) = their particles are checked one by one first. */
+/* Verification of failing box pairs (jobs inside the launch of the density pass of sph_step): mode -1 = automatic (from 500 000
+ * particles on, where a rebuild costs far more than checking a few thousand particle pairs), 0 = never (two boxes that have moved
+ * more than the skin relative to each other ask for the rebuild), 1 = always.  Single-GPU contexts with skin > 0. */
 int  sph_set_verification(sph_ctx *ctx, int mode);
 /* total particles clamped into the domain so far (0 in a healthy run) */
 long long sph_out_of_domain_count(sph_ctx *ctx);

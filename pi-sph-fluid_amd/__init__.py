@@ -462,8 +462,8 @@ class Context:
         return a.value, b.value
 
     def set_verification(self, mode):
-        """True / None (default) / False — box groups whose displacement boxes have moved more than the skin relative to each other
-        are checked particle by particle by the density pass of the step (False: they ask for the rebuild at once)."""
+        """True / False / None (automatic: from 500 000 particles on) — box groups whose displacement boxes have moved more than the
+        skin relative to each other are checked particle by particle inside the launch of the density pass (else they ask for the rebuild)."""
         self._chk(self.L.sph_set_verification(self.h, -1 if mode is None else (1 if mode else 0)))
 
     def rebuild_reasons(self):

@@ -57,7 +57,7 @@ struct sph_ctx {
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
     hipGraph_t graph[8] = {};          // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations)
     hipGraphExec_t gexec[8] = {};
-    int verify_mode = -1;              // the speculative density pass verifies failing box pairs particle by particle: 0 = never (they ask for the rebuild), else yes (sph_set_verification)
+    int verify_mode = -1;              // failing box pairs verified particle by particle (spec_verify_job): -1 = from VERIFY_MIN_PARTICLES on, 0 = never (they ask for the rebuild), 1 = always (sph_set_verification)
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
     bool one_launch_asked = false;  // sph_set_rebuild_launches(ctx, 1): the host vouches that nothing else computes on the device meanwhile
@@ -184,11 +184,15 @@ void refresh_velt(sph_ctx *ctx) {
 //     force + kick + the next step's kick 1/2 + drift (FORCE_KICK_DRIFT), which leaves the displacement boxes for the next check.
 //   The legacy order (ev != nullptr: the profiled step, an event before each kernel in SPH_K_* order; contexts that may share
 //   their device; the direct variant): k_check [+ k_verify], the rebuild as one kernel per phase, density, force.
+constexpr int VERIFY_MIN_PARTICLES = 500000;      // the verify jobs of the density launch: from this many particles on (sph_set_verification)
 bool speculative(const sph_ctx *ctx) { return !ctx->slab && fused(ctx) && ctx->rebuild_wgs > 0; }
 void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (speculative(ctx) && !ev) {
-        launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_ALL, false, true, ctx->verify_mode != 0);
+        // (failing box pairs verified particle by particle: where a rebuild is expensive, i.e. with many particles — 262 144
+        // particles, cfg1: the verify jobs took the launch from 6 to 29 us to save rebuilds of 50 us in one step of a hundred)
+        launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_ALL, false, true,
+                       ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0);
         launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, true);
         launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);
         return;
@@ -332,6 +336,9 @@ int check_flags(sph_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (h[FLAG_BAR_TIMEOUT]) {
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_BAR_TIMEOUT, 0, sizeof(uint32_t), ctx->stream));
+        if (h[FLAG_BAR_TIMEOUT] & 2u)      // (the peer transport's waits have a bit of their own: nothing is wrong with this rank's launches)
+            return fail(ctx, SPH_E_STATE, "peer transport: a neighbouring rank's rebuild word or halo did not arrive within the time limit (is "
+                                          "every rank stepping? sph_slab_peer_reduce / _wait); the state is invalid, upload it again");
         ctx->rebuild_wgs = 0;
         drop_graph(ctx);
         return fail(ctx, SPH_E_STATE, "the one-launch rebuild gave up at a grid barrier: its workgroups were not all resident (is another "

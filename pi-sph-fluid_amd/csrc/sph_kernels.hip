@@ -232,7 +232,9 @@ DEV void adapt_skin(const Consts &c, const uint32_t word, uint32_t *__restrict__
     float skin = dyn[DYN_SKIN];
     if (c.skin_min < c.skin_max && word == (uint32_t)REBUILD_CRITERION && last != 0u) {
         const float T = fmaxf((float)(step - last), 1.0f);
-        const float rhs = ADAPT_RATIO * (skin / c.two_h) / T;
+        // (a skin of 0 — skin_min = 0, or a caller that zeroed the struct and set only `skin` — would stay 0 for ever: rhs = 0;
+        // the rate at which the flow uses up a skin is then taken from a floor of 2 % of 2H)
+        const float rhs = ADAPT_RATIO * (fmaxf(skin, 0.02f * c.two_h) / c.two_h) / T;
         float s = sqrtf(rhs);                                   // s^2 (1 + s) = rhs, Newton from s^2 = rhs
 #pragma unroll
         for (int it = 0; it < 4; it++) s -= (s * s * (1.0f + s) - rhs) / (s * (2.0f + 3.0f * s) + 1e-12f);
@@ -1043,7 +1045,7 @@ DEV bool peer_wait(const uint32_t *__restrict__ word, const uint32_t tag, const 
         if ((value >> shift) == tag) return true;
         __builtin_amdgcn_s_sleep(4);
         if (++spins > PEER_SPINS) {
-            atomicOr(&flags[FLAG_BAR_TIMEOUT], 1u);
+            atomicOr(&flags[FLAG_BAR_TIMEOUT], 2u);      // (bit 1: a peer never arrived; bit 0 is the grid barrier's)
             return false;
         }
     }

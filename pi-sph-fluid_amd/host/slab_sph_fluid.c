@@ -671,6 +671,8 @@ static int rebalance(rank_state *rs, float gx, float gy, double min_gain, int *m
     HIPCHK(hipStreamSynchronize(rs->xst));
     sph_destroy(rs->ctx);
     CHK(make_context(rs, cuts[cm->rank], cuts[cm->rank + 1], loc, lid, (long)n_in, gx, gy));
+    HIPCHK(hipStreamSynchronize(rs->st));
+    CHK(comm_barrier(cm));      /* (nobody steps before every rank has its new context: see main) */
     *moved = 1;
     for (int q = 0; q < n; q++) free(out[q]);
     free(out); free(cnt); free(in); free(loc); free(lid);
@@ -834,6 +836,10 @@ int main(int argc, char **argv) {
     if (transport == TR_PEER) CHK(peer_setup(&rs, halo_bytes));
     const double t_create = now_s();
     CHK(make_context(&rs, c0, c1, loc, ids, n_loc, gx, gy));
+    /* (every rank has its context before anybody steps: the peer transport's first wait of a step is bounded, and a rank whose
+     * context creation lags must not run its neighbours into that bound) */
+    HIPCHK(hipStreamSynchronize(rs.st));
+    CHK(comm_barrier(&rs.cm));
     int n_local = 0, n_owned = 0;
     SPHCHK(rs.ctx, sph_slab_counts(rs.ctx, &n_local, &n_owned));
     fprintf(stderr, "[rank %d] columns [%d,%d) of %d, lattice columns [%ld,%ld), local/owned %d/%d, created in %.2f s, halo buffers %zu B, device %d, %s transport\n",
@@ -855,7 +861,9 @@ int main(int argc, char **argv) {
             /* the two heavy kernels at the start of the timed region (back-to-back launches on the live state; again at
              * the end: the JSON line reports their mean) — and enough of them that a fresh GPU has reached its running
              * clocks when a short window (the driver's 20 steps) begins: bench.py does the same at N = 1 */
-            if (s > 0 && pre_reps > 0) {
+            if (s > 0 && pre_reps > 0) {      /* (EVERY rank: one-sided work between two steps would leave the others waiting in theirs) */
+                HIPCHK(hipStreamSynchronize(rs.st));
+                CHK(comm_barrier(&rs.cm));
                 SPHCHK(rs.ctx, sph_time_kernel(rs.ctx, SPH_K_DENSITY_EOS, pre_reps, &dens0_ms));
                 SPHCHK(rs.ctx, sph_time_kernel(rs.ctx, SPH_K_FORCE_KICK, pre_reps, &force0_ms));
             }
