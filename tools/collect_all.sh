@@ -1,0 +1,24 @@
+#!/usr/bin/env bash
+# tools/collect_all.sh <round tag, e.g. r04> — on the GPU box: every rocprofv3 summary the round commits under profiles/
+# (kernel trace + separate PMC passes per regime: profiles/collect.sh), developed flows from checkpoints written outside the
+# profiler.  Raw output under gpurun_out/prof_<tag>_*; summaries under gpurun_out/<tag>_*_summary.md and gpurun_out/traffic.json.
+set -uo pipefail
+R="${1:-r04}"
+root="${GRAFT_REPO_ROOT:-$(pwd)}"
+cd "$root"
+cp profiles/traffic.json gpurun_out/traffic.json
+sum() { python3 profiles/summarize.py "gpurun_out/prof_$1" "gpurun_out/$1_rocprofv3_summary.md" gpurun_out/traffic.json "$2" "$3" > /dev/null; echo "== $1"; head -14 "gpurun_out/$1_rocprofv3_summary.md"; }
+# cfg2: the default window's early part (steps 100-400)
+profiles/collect.sh ${R}_cfg2 > /dev/null 2>&1; sum ${R}_cfg2 cfg2 "--steps 300 --warmup 100"
+# the driver's command: 20 steps after 5, the fluid at rest
+SPH_PROF_WARM=5 SPH_PROF_STEPS=20 SPH_PROF_PMC_WARM=5 profiles/collect.sh ${R}_cfg2_at_rest > /dev/null 2>&1; sum ${R}_cfg2_at_rest cfg2_at_rest "--steps 20 --warmup 5"
+# developed flow of cfg2 from a checkpoint after 4000 steps
+python3 bench.py --no-cpu --no-also --steps 1 --warmup 4000 --save-state /tmp/ck_cfg2.npz > /dev/null 2>&1
+SPH_PROF_WARM=100 SPH_PROF_STEPS=300 SPH_PROF_PMC_WARM=100 profiles/collect.sh ${R}_cfg2_developed --load-state /tmp/ck_cfg2.npz > /dev/null 2>&1; sum ${R}_cfg2_developed cfg2_developed "--load-state <checkpoint after 4000 steps> --steps 300 --warmup 100"
+# cfg1
+profiles/collect.sh ${R}_cfg1 --workload cfg1 > /dev/null 2>&1; sum ${R}_cfg1 cfg1 "--workload cfg1 --steps 300 --warmup 100"
+# cfg4 on one GPU (at rest under the tilt), and developed (checkpoint after 2000 steps)
+SPH_PROF_WARM=50 SPH_PROF_STEPS=100 profiles/collect.sh ${R}_cfg4 --workload cfg4 --tilt > /dev/null 2>&1; sum ${R}_cfg4 cfg4 "--workload cfg4 --tilt --steps 100 --warmup 50"
+python3 bench.py --no-cpu --no-also --workload cfg4 --tilt --steps 1 --warmup 2000 --save-state /tmp/ck_cfg4.npz > /dev/null 2>&1
+SPH_PROF_WARM=30 SPH_PROF_STEPS=100 SPH_PROF_PMC_WARM=30 profiles/collect.sh ${R}_cfg4_developed --workload cfg4 --tilt --load-state /tmp/ck_cfg4.npz > /dev/null 2>&1; sum ${R}_cfg4_developed cfg4_developed "--workload cfg4 --tilt --load-state <checkpoint after 2000 steps> --steps 100 --warmup 30"
+ls -la gpurun_out/*_summary.md
