@@ -7,7 +7,12 @@ R="${1:-r04}"
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$root"
 cp profiles/traffic.json gpurun_out/traffic.json
-sum() { python3 profiles/summarize.py "gpurun_out/prof_$1" "gpurun_out/$1_rocprofv3_summary.md" gpurun_out/traffic.json "$2" "$3" > /dev/null; echo "== $1"; head -14 "gpurun_out/$1_rocprofv3_summary.md"; }
+sum() {
+    python3 profiles/summarize.py "gpurun_out/prof_$1" "gpurun_out/$1_rocprofv3_summary.md" gpurun_out/traffic.json "$2" "$3" > /dev/null
+    cp "gpurun_out/prof_$1/trace/trace_kernel_stats.csv" "gpurun_out/$1_kernel_stats.csv" 2>/dev/null
+    rm -rf "gpurun_out/prof_$1"      # (the raw traces are tens of MB each: gpurun merges at most 64 MiB back)
+    echo "== $1"; head -14 "gpurun_out/$1_rocprofv3_summary.md"
+}
 # cfg2: the default window's early part (steps 100-400)
 profiles/collect.sh ${R}_cfg2 > /dev/null 2>&1; sum ${R}_cfg2 cfg2 "--steps 300 --warmup 100"
 # the driver's command: 20 steps after 5, the fluid at rest
