@@ -488,8 +488,6 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     a.vq = nullptr;
     if (!slab) { ALLOC(a.vq, 2 + 2 * (size_t)VQ_CAP); }
-    a.rmask = nullptr;
-    if (!slab) { ALLOC(a.rmask, nwaves); }
     a.djobs[0] = a.djobs[1] = nullptr;
     a.pos_first = a.pos;
     if (!slab) { ALLOC(a.djobs[0], 1); ALLOC(a.djobs[1], 1); }

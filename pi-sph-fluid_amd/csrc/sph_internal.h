@@ -112,7 +112,6 @@ struct Arrays {
     uint32_t *check;    // word: somebody moved more than skin/2 -> k_check compares the wave boxes (single GPU)
     uint32_t *rebuild;  // the rebuild request word: flags + FLAG_REBUILD, or (slab mode) a word of the host framework
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
-    uint32_t *rmask;    // per box group: list rows in which some lane has a neighbour inside the support now (density pass -> force pass of the same step; single-GPU contexts)
     SpecJobs *djobs[2]; // see SpecJobs (single-GPU contexts): [0] with pos = pos_first, [1] with the alternate set (filled once at creation)
     float2 *pos_first;  // what pos pointed at when the context was created
     uint32_t *vq;       // verification queue (spec_check_job -> spec_verify_job): [0] count, [2 + 2 e ..] = (group, failing neighbour group); nullptr: slabs
