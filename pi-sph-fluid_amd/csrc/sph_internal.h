@@ -188,7 +188,10 @@ constexpr int LIST_WORDS_PER_TILE = 12 * SPH_TILE_PARTICLES;   // LROWS4 x TP (s
 constexpr int XRANGE_WORDS = 260;                              // 4 RMAX + 1 prefix sums, 4 RMAX first particles (sph_list.inc)
 constexpr int STAB_ENTRIES_PER_TILE = 896;                     // staging-table entries per tile (sph_list.inc)
 constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle list padding points at (finite: no NaN)
-constexpr int VQ_CAP = 4096;    // pairs of groups the verification queue holds (more: rebuild)
+#ifndef SPH_VQ_CAP
+#define SPH_VQ_CAP 4096
+#endif
+constexpr int VQ_CAP = SPH_VQ_CAP;    // pairs of groups the verification queue holds (more: rebuild)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer
 constexpr int HALO_REC = 5;     // words per halo record
 
