@@ -1483,3 +1483,20 @@ void launch_metaballs(hipStream_t st, const Consts &c, const Arrays &a, float wi
 }
 
 }  // namespace sph
+
+#ifdef SPH_SPEC_TRACE
+// measurement builds only: the begin / end clock of the first `wgs` workgroups of the last speculative density launch (100 MHz
+// ticks; 2 words each) and the verify jobs' counters (4 words, summed over their waves), read and reset.  The caller has synchronised.
+extern "C" int sph_spec_trace(unsigned long long *out, int wgs, unsigned int *counts) {
+    if (wgs > sph::SPEC_TRACE_WGS) wgs = sph::SPEC_TRACE_WGS;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_spec_trace), sizeof(unsigned long long) * 2 * (size_t)wgs) != hipSuccess) return -1;
+    static unsigned int per_wave[sph::SPEC_TRACE_WGS][4];
+    if (hipMemcpyFromSymbol(per_wave, HIP_SYMBOL(sph::g_spec_trace_n), sizeof per_wave) != hipSuccess) return -1;
+    counts[0] = counts[1] = counts[2] = counts[3] = 0u;
+    for (int w = 0; w < sph::SPEC_TRACE_WGS; w++)
+        for (int k = 0; k < 3; k++) counts[k] += per_wave[w][k];
+    for (int w = 0; w < sph::SPEC_TRACE_WGS; w++) per_wave[w][0] = per_wave[w][1] = per_wave[w][2] = per_wave[w][3] = 0u;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sph::g_spec_trace_n), per_wave, sizeof per_wave) != hipSuccess) return -1;
+    return wgs;
+}
+#endif
