@@ -542,9 +542,10 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
         if (a.vq) HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (2 + 2 * (size_t)VQ_CAP), st));
         if (a.djobs[0]) {
-            const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, a.pos, a.pos_ref};
+            const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, a.pos, a.pos_ref, a.vel, a.uref};
             SpecJobs j1 = j0;
             j1.pos = a.pos2;
+            j1.vel = a.vel2;
             HIPCHK(ctx, hipMemcpyAsync(a.djobs[0], &j0, sizeof j0, hipMemcpyHostToDevice, st));
             HIPCHK(ctx, hipMemcpyAsync(a.djobs[1], &j1, sizeof j1, hipMemcpyHostToDevice, st));
             HIPCHK(ctx, hipStreamSynchronize(st));      // (locals)

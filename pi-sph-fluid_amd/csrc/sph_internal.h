@@ -62,6 +62,8 @@ struct SpecJobs {
     const uint32_t *check, *dn;
     const uint2 *lrec;
     const float2 *pos, *pos_ref;
+    const float2 *vel;      // (pos and vel of ONE orientation of the two sets)
+    float *uref;            // the reference displacement of this step's force pass (sample_uref; null: the absolute criterion)
 };
 
 struct Arrays {
