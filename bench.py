@@ -74,8 +74,9 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
     prm, f, b = sph.scene(name) if name != "cfg2" else sph.dam_break(1)
     if skin is not None:
         prm.skin = prm.skin_min = skin      # a fixed skin
-    elif os.environ.get("SPH_BENCH_SKIN_MIN"):      # (sweeps: the smallest skin of the adaptive range)
-        prm.skin_min = float(os.environ["SPH_BENCH_SKIN_MIN"])
+    elif os.environ.get("SPH_BENCH_SKIN_MIN") or os.environ.get("SPH_BENCH_SKIN_MAX"):      # (sweeps: the ends of the adaptive range)
+        prm.skin_min = float(os.environ.get("SPH_BENCH_SKIN_MIN", prm.skin_min))
+        prm.skin = float(os.environ.get("SPH_BENCH_SKIN_MAX", prm.skin))
     n = len(f)
     grav = sph.GravitySource(sph.GRAVITY_TILT, 9.81) if tilt else None
     dt_sim = float(np.float32(prm.dt))
