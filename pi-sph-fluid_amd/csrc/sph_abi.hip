@@ -53,6 +53,7 @@ struct sph_ctx {
     bool primed = false;
     bool p_stale = false;        // the density passes of a step do not store p: refresh_p() before use
     bool velt_stale = false;     // the fused force pass does not store the velocity between steps: refresh_velt() before use
+    bool acc_stale = false;      // ... nor the acceleration: refresh_acc() before use, and before anything it depends on changes
     bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
     hipGraph_t graph[8] = {};          // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations)
@@ -171,7 +172,16 @@ void refresh_p(sph_ctx *ctx) {
     if (ctx->p_stale) launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, false);
     ctx->p_stale = false;
 }
+// a of the last step (:303-373): the fused force pass has used it for its kicks and has not stored it.  The state it was
+// computed from — positions, half-kicked velocities, rho, p, walls, gravity, lists — is untouched until the next step or until
+// a caller changes one of them (every entry point that does calls this first), and the same kernel in its FORCE_EVAL form
+// walks the same lists in the same order.
+void refresh_acc(sph_ctx *ctx) {
+    if (ctx->acc_stale) launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, FORCE_EVAL, ctx->variant);
+    ctx->acc_stale = false;
+}
 void refresh_velt(sph_ctx *ctx) {
+    refresh_acc(ctx);
     if (ctx->velt_stale) launch_refresh_velt(ctx->stream, ctx->c, ctx->a, ctx->cap);
     ctx->velt_stale = false;
 }
@@ -308,6 +318,7 @@ int run_step(sph_ctx *ctx, hipEvent_t *ev) {
     }
     ctx->primed = fused(ctx);
     ctx->velt_stale = fused(ctx);
+    ctx->acc_stale = fused(ctx);
     ctx->p_stale = true;
     ctx->stepped = true;
     hipGraphExec_t g = ev ? nullptr : step_graph(ctx);
@@ -673,6 +684,7 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
             if (g) {
                 HIPCHK(ctx, hipGraphLaunch(g, ctx->stream));
                 ctx->velt_stale = true;
+                ctx->acc_stale = true;
                 ctx->p_stale = true;
                 s += m;
                 continue;
@@ -708,6 +720,7 @@ int sph_read_accel(sph_ctx *ctx, float *du_dt, float *dv_dt) {
     if (!ctx || !ctx->stream || ((!du_dt || !dv_dt) && ctx->n)) return SPH_E_ARG;
     if (ctx->slab) return fail(ctx, SPH_E_STATE, "slab context: use sph_slab_read");
     (void)hipSetDevice(ctx->device);
+    refresh_acc(ctx);
     launch_unsort_accel(ctx->stream, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
     HIPCHK(ctx, hipMemcpyAsync(du_dt, ctx->d_du, (size_t)ctx->n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dv_dt, ctx->d_dv, (size_t)ctx->n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -730,6 +743,7 @@ int sph_update_boundary(sph_ctx *ctx, const sph_particle *boundary) {
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     Arrays &a = ctx->a;
+    refresh_acc(ctx);      // (a of the last step belongs to the walls as they were)
     const size_t nb = (size_t)ctx->nb;
     std::vector<float2> hb(nb ? nb : 1), hbv(nb ? nb : 1);
     for (size_t i = 0; i < nb; i++) {
@@ -759,6 +773,7 @@ int sph_set_boundary_velocity(sph_ctx *ctx, float u, float v) {
     if (!(std::isfinite(u) && std::isfinite(v))) return fail(ctx, SPH_E_ARG, "sph_set_boundary_velocity: velocity not finite");
     if (ctx->slab && ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_set_boundary_velocity mid-step");
     (void)hipSetDevice(ctx->device);
+    refresh_acc(ctx);      // (a of the last step belongs to the wall velocity as it was)
     launch_fill_float2(ctx->stream, ctx->a.bvel, u, v, ctx->nb);            // bin order: what the force pass reads
     launch_fill_float2(ctx->stream, ctx->d_bvel_in, u, v, ctx->nb);         // original order: what sph_update_boundary re-bins
     HIPCHK(ctx, hipGetLastError());
@@ -945,6 +960,7 @@ int sph_upload_state(sph_ctx *ctx, const sph_particle *fluid) {
     hipStream_t st = ctx->stream;
     // du_dt, dv_dt stay with their particles (reference: index-aligned arrays, :616): out to original order before
     // the arrays are rewritten, back in through the new sort order afterwards
+    refresh_acc(ctx);
     launch_unsort_accel(st, ctx->a, ctx->n, ctx->d_du, ctx->d_dv);
     ctx->velt_stale = false;      // velt is rewritten below
     ctx->p_stale = false;         // ... and so are rho and p
@@ -979,6 +995,7 @@ int sph_upload_accel(sph_ctx *ctx, const float *du_dt, const float *dv_dt) {
 int sph_eval_density(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
+    refresh_acc(ctx);             // a of the last step, while the rho and p it was computed from are still there
     refresh_p(ctx);               // the stored p, while the rho it belongs to is still there
     launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO, ctx->variant, false);
     launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, true);   // keep p/rho^2 consistent with the new rho and the stored p
@@ -989,6 +1006,7 @@ int sph_eval_density(sph_ctx *ctx) {
 int sph_eval_pressure(sph_ctx *ctx) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
+    refresh_acc(ctx);
     launch_eos(ctx->stream, ctx->c, ctx->a, ctx->cap, false);
     ctx->p_stale = false;
     HIPCHK(ctx, hipGetLastError());
@@ -1144,6 +1162,7 @@ int sph_slab_step_end(sph_ctx *ctx) {
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, ctx->slab_overlapped ? DENS_REST : DENS_ALL, false);
     launch_force(st, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     ctx->velt_stale = fused(ctx);
+    ctx->acc_stale = fused(ctx);
     ctx->p_stale = true;
     ctx->stepped = true;
     HIPCHK(ctx, hipGetLastError());

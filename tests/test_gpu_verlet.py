@@ -246,6 +246,49 @@ def test_host_synchronisation_points_do_not_change_the_run(sph, orc):
             assert np.array_equal(got[k], ref[k]), (scene, k)
 
 
+def test_acceleration_of_the_fused_step_is_recomputed_on_demand(sph, orc):
+    """The fused force pass (kick + the next step's kick 1/2 + drift) does not store du_dt, dv_dt — nothing in the step loop reads
+    them; a read-back gets them from the same kernel in its evaluate-only form on the untouched state of the last step.  The
+    collapsing dam after 150 steps: sph_read_accel equals the stored accelerations of the same step taken by the kernels that do
+    store them (the direct variant's step from the same state), twice the same bits, the full-step velocity of sph_read_particles
+    is v_half + DT/2 a, and entry points that change what a depends on (sph_eval_density, sph_update_boundary) leave the a of the
+    last step in place."""
+    prm, f, b, g = block_scene(sph, orc, None)
+    prm.deterministic = 1
+    half_dt = 0.5 * float(np.float32(prm.dt))
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.step(149, GX, GY)
+        ctx.sync()
+        before = ctx.read_particles()
+        bdu, bdv = ctx.read_accel()
+        ctx.step(1, GX, GY)                         # fused: a of this step is not stored
+        du1, dv1 = ctx.read_accel()                 # ... recomputed here
+        du2, dv2 = ctx.read_accel()
+        assert np.array_equal(du1, du2) and np.array_equal(dv1, dv2)
+        after = ctx.read_particles()
+        assert np.abs(du1).max() > 1.0 and not np.array_equal(du1, bdu)
+        # the same step by kernels that store a: the direct variant from the state before it
+        with sph.Context(prm, f, b, GX, GY) as ref:
+            ref.upload_state(before)
+            ref.upload_accel(bdu, bdv)
+            ref.set_variant(1)
+            ref.step(1, GX, GY)
+            rdu, rdv = ref.read_accel()
+            rafter = ref.read_particles()
+        scale = np.hypot(rdu, rdv) + 9.81 + 0.05 * (rafter["p"] + rafter["p"].mean())
+        assert np.max(np.hypot(du1 - rdu, dv1 - rdv) / scale) <= 1e-4
+        assert np.max(np.abs(after["x"] - rafter["x"])) <= 1e-5 and np.max(np.abs(after["u"] - rafter["u"])) <= 2e-3
+        # things a depends on may change afterwards: the a of the last step is fixed first
+        ctx.step(1, GX, GY)
+        ctx.eval_density()                          # (rewrites rho in another summation order)
+        du3, dv3 = ctx.read_accel()
+        ctx.step(0, GX, GY)
+        with sph.Context(prm, f, b, GX, GY) as again:
+            again.step(151, GX, GY)
+            du4, dv4 = again.read_accel()
+        assert np.array_equal(du3, du4) and np.array_equal(dv3, dv4)
+
+
 def test_coherent_motion_keeps_lists(sph, orc, oracle):
     """a block moving as a whole at 30 m/s (0.5 skin/2 per step at the default skin): the absolute criterion would
     rebuild every other step; the relative one (per-wave displacement boxes) keeps the lists for many steps.  Results
