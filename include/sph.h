@@ -110,7 +110,9 @@ int  sph_sync(sph_ctx *ctx);
 /* Read-back in ORIGINAL particle order (what main() reads from fluid[] at :649, :657-671).
  * out[i] = {x,y,u,v,m,rho,p} of the particle given as fluid[i] to sph_create. */
 int  sph_read_particles(sph_ctx *ctx, sph_particle *out);
-/* du_dt[], dv_dt[] of :492-493, original order */
+/* du_dt[], dv_dt[] of :492-493, original order.  (The step loop does not keep them in memory — its force pass uses them for its
+ * kicks and moves on; this call, and the velocity of sph_read_particles / sph_stats, evaluates them once more on the state the last
+ * step left: one force pass, then the copy.) */
 int  sph_read_accel(sph_ctx *ctx, float *du_dt, float *dv_dt);
 /* boundary particles, original order, psi in .m (:259) */
 int  sph_read_boundary(sph_ctx *ctx, sph_particle *out);
