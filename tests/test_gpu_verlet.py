@@ -289,6 +289,27 @@ def test_acceleration_of_the_fused_step_is_recomputed_on_demand(sph, orc):
         assert np.array_equal(du3, du4) and np.array_equal(dv3, dv4)
 
 
+def test_no_viscosity_is_exactly_no_viscous_term(sph, orc):
+    """alpha = 0 (sph_params.alpha, :334): the list kernels stage the densities of a tile divided by the viscous factor -2 alpha c h
+    (which takes one multiplication out of every pair); with alpha = 0 that factor is 0, the staged densities are infinite and the
+    viscous term must come out as exactly 0 — a and the trajectory against the direct variant (which multiplies by 0), all finite."""
+    prm, f, b, g = block_scene(sph, orc, None)
+    prm.alpha = 0.0
+    with sph.Context(prm, f, b, GX, GY) as ctx, sph.Context(prm, f, b, GX, GY) as ref:
+        ref.set_variant(1)
+        for c_ in (ctx, ref):
+            c_.step(120, GX, GY)
+            c_.sync()
+        got, want = ctx.read_particles(), ref.read_particles()
+        gdu, gdv = ctx.read_accel()
+        wdu, wdv = ref.read_accel()
+        assert np.all(np.isfinite(gdu)) and np.all(np.isfinite(gdv)) and np.all(np.isfinite(got["x"]))
+        assert np.hypot(got["u"], got["v"]).max() > 0.3
+        assert np.max(np.abs(got["x"] - want["x"])) <= 1e-4 and np.max(np.abs(got["rho"] - want["rho"]) / want["rho"]) <= 1e-5
+        scale = np.hypot(wdu, wdv) + 9.81 + 0.05 * (want["p"] + want["p"].mean())
+        assert np.max(np.hypot(gdu - wdu, gdv - wdv) / scale) <= 1e-3
+
+
 def test_coherent_motion_keeps_lists(sph, orc, oracle):
     """a block moving as a whole at 30 m/s (0.5 skin/2 per step at the default skin): the absolute criterion would
     rebuild every other step; the relative one (per-wave displacement boxes) keeps the lists for many steps.  Results
