@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md "HBM3E peak BW"); ~6290 GB/s measured copy
 VALU_CYCLES, TRANS_CYCLES, N_SIMD, CLOCK_GHZ = 2.67, 8.75, 1024, 2.4      # tools/ubench_valu on MI355X; 256 CUs x 4 SIMDs
-TRANS_SHARE = {"force_kick": 2.0 / 33.0, "density_eos": 1.0 / 14.0}      # transcendental instructions among a walker's VALU instructions (from the ISA)
+TRANS_SHARE = {"force_kick": 2.0 / 29.0, "density_eos": 1.0 / 14.0}      # transcendental instructions among a walker's VALU instructions (from the ISA)
 
 
 def log(*a):
@@ -184,7 +184,7 @@ def roofline(sph, res, traffic_key=None):
             if v:      # the secondary ceiling: VALU issue.  SQ_INSTS_VALU wave-instructions per launch over 1024 SIMDs at the issue
                        # cost tools/ubench_valu measures on this part (2.67 cycles a plain f32 operation, 8.75 a transcendental one)
                 if not v.get("trans"):      # (SQ_INSTS_VALU_TRANS reads 0 on this stack: the share from the kernels' code — the force pass
-                    v = dict(v, trans=int(v["insts"] * TRANS_SHARE.get(dom, 0.0)))      # issues v_sqrt + v_rcp per ~33 instructions of a list entry, the density pass v_sqrt per ~14)
+                    v = dict(v, trans=int(v["insts"] * TRANS_SHARE.get(dom, 0.0)))      # issues v_sqrt + v_rcp per ~29 instructions of a list entry, the density pass v_sqrt per ~14)
                 cyc = ((v["insts"] - v["trans"]) * VALU_CYCLES + v["trans"] * TRANS_CYCLES) / N_SIMD
                 busy_us = cyc / CLOCK_GHZ / 1e3
                 valu = {"wave_insts_per_launch": v["insts"], "transcendental": v["trans"], "issue_us": round(busy_us, 2),
