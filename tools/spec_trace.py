@@ -24,7 +24,7 @@ tiles = (n + 255) // 256
 tiles_grid = (tiles + 63) // 64 * 64
 nw = (n + 63) // 64
 ncheck = min(256, max(8, ((nw * 8 + 255) // 256 + 7) & ~7))      # spec_check_wgs (sph_list.inc): CHECK_LANES = 8
-nverify = min(1024, max(8, (nw // 4 + 7) & ~7))
+nverify = min(int(os.environ.get("SPH_TRACE_VERIFY_WGS", "512")), max(8, (nw // 4 + 7) & ~7))      # spec_verify_wgs (SPH_SPEC_VERIFY_WGS)
 tiles_a = (tiles_grid * int(os.environ.get("SPH_TRACE_AT", "5")) // 8) & ~7
 grid = ncheck + tiles_grid + nverify
 buf = np.zeros((grid, 2), dtype=np.uint64)
