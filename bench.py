@@ -107,7 +107,12 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
         np.savez(save_state, particles=ctx.read_particles(), du=du_, dv=dv_)
     # the two heavy kernels at the START of the timed region (back-to-back launches of the idempotent kernels on the live
     # state); again at its end below: their mean is the figure for "the kernel's average duration over the timed region"
-    k_begin = (ctx.time_kernel("density_eos", PRE_REPS), ctx.time_kernel("force_kick", PRE_REPS)) if warmup > 0 and not load_state else None
+    def spec_ms(reps):      # the density launch as the step issues it (speculative, with the criterion's jobs) + its reset launch
+        try:
+            return ctx.time_kernel("density_spec", reps)
+        except sph.SphError:
+            return None
+    k_begin = (ctx.time_kernel("density_eos", PRE_REPS), ctx.time_kernel("force_kick", PRE_REPS), spec_ms(50)) if warmup > 0 and not load_state else None
     rates, rebuilt = [], []
     v_begin, why_begin = ctx.verify_stats(), ctx.rebuild_reasons()
     for _ in range(windows):
@@ -129,11 +134,16 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
     kt["profiled_step_separate_launches"] = kt.pop("step")
     # the two heavy kernels are idempotent: time back-to-back launches on the live state (no per-launch
     # event overhead; this is the figure that must agree with rocprofv3's average kernel duration)
-    k_end = (ctx.time_kernel("density_eos", 50), ctx.time_kernel("force_kick", 50))
+    k_end = (ctx.time_kernel("density_eos", 50), ctx.time_kernel("force_kick", 50), spec_ms(50))
     if k_begin is None:
         k_begin = k_end
     kt["density_eos"] = 0.5 * (k_begin[0] + k_end[0])
     kt["force_kick"] = 0.5 * (k_begin[1] + k_end[1])
+    # density_eos: the plain pass (the tiles alone).  What sph_step launches on this context is the SPECULATIVE pass — the same
+    # tiles plus the check / verify jobs of the rebuild criterion as extra workgroups (rocprofv3: k_density_list<1, 0, true>) —
+    # timed here back to back with the one-thread launch that resets the jobs' words between two of them (sph_diag.h)
+    if k_begin[2] is not None and k_end[2] is not None:
+        kt["density_spec_launch_plus_reset"] = 0.5 * (k_begin[2] + k_end[2])
     kt["density_eos_at_begin_end"] = [round(k_begin[0], 5), round(k_end[0], 5)]
     kt["force_kick_at_begin_end"] = [round(k_begin[1], 5), round(k_end[1], 5)]
     max_rho, max_speed = ctx.stats()
@@ -400,30 +410,74 @@ def launch_ranks(args):
     return 0
 
 
-N1_CACHE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sph_bench_n1_%d.json" % os.getuid())
+N1_CACHE = os.environ.get("SPH_BENCH_N1_CACHE") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "sph_bench_n1_%d.json" % os.getuid())
+
+# The one-GPU references of the N > 1 legs, by leg: the scene, the gravity and the EXACT window (warm-up steps, steps per window,
+# windows: the rate is the median window) a leg is timed on.  A speed-up is only ever formed between two runs of the same window —
+# cfg4 at rest (steps 50-650) runs at nearly twice the rate of its developed flow (steps 2000-2600).
+STRONG_LEGS = {"at_rest": ("cfg4_at_rest", 50, 200, 3), "developed": ("cfg4_developed", 2000, 200, 3)}
+if os.environ.get("SPH_BENCH_STRONG_DEVELOPED"):      # (rehearsals: "warmup,steps,windows" of the developed strong leg)
+    STRONG_LEGS["developed"] = ("cfg4_developed",) + tuple(int(x) for x in os.environ["SPH_BENCH_STRONG_DEVELOPED"].split(","))
+
+
+def n1_leg(tps, warmup, steps, windows):
+    return {"timesteps_per_s": round(float(tps), 2), "warmup": int(warmup), "steps": int(steps), "windows": int(windows)}
 
 
 def cached_n1():
-    """what the N = 1 run of bench.py measured on this host ({"cfg2": steps/s of the 8(d) protocol, "cfg4": steps/s on one GPU}):
-    the references of the N > 1 runs' speed-ups (they do not measure N = 1 again)"""
+    """what the N = 1 run of bench.py measured on this host, by leg (see write_n1_cache); {} when there is none"""
     try:
         with open(N1_CACHE) as fh:
-            return json.load(fh)
-    except (OSError, ValueError):
+            d = json.load(fh)
+        return d.get("legs", {}) if d.get("schema") == 2 else {}
+    except (OSError, ValueError, AttributeError):
         return {}
 
 
-def c_host_cmd(host, scene, steps, warmup, transport, tilt, breakdown=30):
-    cmd = [host, "--scene", scene, "--steps", str(steps), "--warmup", str(warmup), "--transport", transport, "--breakdown", str(breakdown)]
+def write_n1_cache(legs):
+    try:
+        with open(N1_CACHE, "w") as fh:
+            json.dump({"schema": 2, "written_by": "the N = 1 run of bench.py on this host", "legs": legs}, fh)
+    except OSError:
+        pass
+
+
+def one_gpu_reference(sph, key, warmup, steps, windows, measure=True):
+    """timesteps/s of ONE GPU (sph_step, the fastest one-GPU path) on the window a multi-GPU leg was timed on: the figure the N = 1
+    run of this host cached for exactly that window, else measured here and now on device 0 (the multi-rank legs are over: the
+    GPU is free) — never a figure from another window."""
+    e = cached_n1().get(key)
+    if e and (e.get("warmup"), e.get("steps"), e.get("windows")) == (warmup, steps, windows) and e.get("timesteps_per_s", 0) > 0:
+        return {"timesteps_per_s": e["timesteps_per_s"], "reference": "cached by the N = 1 run of bench.py on this host (same window)",
+                "window": [warmup, steps, windows]}
+    if not measure:
+        return None
+    try:
+        t0 = time.time()
+        if key == "cfg2_window":
+            r = run_single(sph, "cfg2", steps, warmup, windows=windows)
+        else:
+            r = run_single(sph, "cfg4", steps, warmup, profile_steps=5, tilt=True, windows=windows)
+        log("one-GPU reference %s measured in %.1f s: %.2f steps/s" % (key, time.time() - t0, r["steps_per_s"]))
+        return {"timesteps_per_s": round(r["steps_per_s"], 2), "reference": "measured in this run (sph_step on device 0, same window)",
+                "window": [warmup, steps, windows], "window_timesteps_per_s": r["window_steps_per_s"]}
+    except Exception as e_:      # (reported, never raised: the multi-GPU figures stand on their own)
+        log("one-GPU reference %s failed: %r" % (key, e_))
+        return {"timesteps_per_s": None, "reference": "unavailable: %r" % (e_,), "window": [warmup, steps, windows]}
+
+
+def c_host_cmd(host, scene, steps, warmup, transport, tilt, breakdown=30, windows=1):
+    cmd = [host, "--scene", scene, "--steps", str(steps), "--warmup", str(warmup), "--windows", str(windows), "--transport", transport,
+           "--breakdown", str(breakdown)]
     if tilt:
         cmd.append("--tilt")
     return cmd
 
 
-def c_host_run(host, scene, steps, warmup, transport, tilt, world_env, tag):
+def c_host_run(host, scene, steps, warmup, transport, tilt, world_env, tag, windows=1):
     """one run of the C multi-GPU host; returns (returncode, parsed JSON line or None, rank).  Under a launcher (world_env: this
     process is one rank of WORLD_SIZE) it runs the one rank; else it starts its own ranks."""
-    cmd = c_host_cmd(host, scene, steps, warmup, transport, tilt)
+    cmd = c_host_cmd(host, scene, steps, warmup, transport, tilt, windows=windows)
     world, rank = world_env
     if world and transport == "rccl":          # torchrun started the ranks: this process is one of them
         # one file per job and leg: the launcher's run id (and port) name it; rank 0 removes it once every rank has joined
@@ -439,11 +493,12 @@ def c_host_run(host, scene, steps, warmup, transport, tilt, world_env, tag):
     return r.returncode, (json.loads(lines[-1]) if lines else None)
 
 
-def leg_summary(d, world, reference_tps=None, weak=False):
-    """the figures of one C-host run for the JSON line; speed-up against the N = 1 figure of the same scene (strong) or
-    efficiency against N x the one-GPU rate (weak), when the N = 1 run of this host left one"""
+def leg_summary(d, world, ref=None, weak=False):
+    """the figures of one C-host run for the JSON line.  ref (one_gpu_reference): the one-GPU rate on the SAME window — speed-up
+    against it (strong) or efficiency against it (weak: N x the particles at the one-GPU rate would be efficiency 1)"""
     out = {"value": round(d["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s", "timesteps_per_s": round(d["ticks_per_s"], 2),
            "ms_per_step": d["ms_per_step"], "workload": d["workload"], "n_fluid": d["n_fluid"], "host": d["host"],
+           "window": [d.get("warmup"), d.get("steps"), d.get("windows", 1)], "window_timesteps_per_s": d.get("window_ticks_per_s"),
            "particles_conserved": d["particles_conserved"], "neighbour_rebuilds": d["neighbour_rebuilds"],
            "halo_buffer_bytes": d.get("halo_buffer_bytes"),
            "kernel_ms": {"density_eos": d.get("rank0_density_ms"), "force_kick": d.get("rank0_force_ms")},
@@ -451,13 +506,15 @@ def leg_summary(d, world, reference_tps=None, weak=False):
            # `breakdown_steps` extra steps with an event at every phase boundary): a long begin / end = this rank's own kernels
            # (overloaded: re-balance), long reduce / exchange everywhere = waiting for the others / the interconnect
            "breakdown_steps": d.get("breakdown_steps"), "per_rank": d.get("per_rank")}
-    if reference_tps:
-        if weak:
-            out["one_gpu_timesteps_per_s"] = reference_tps
-            out["weak_efficiency_vs_1gpu"] = round(d["ticks_per_s"] / reference_tps, 4)
-        else:
-            out["one_gpu_timesteps_per_s"] = reference_tps
-            out["speedup_vs_1gpu"] = round(d["ticks_per_s"] / reference_tps, 3)
+    if ref:
+        out["reference"] = ref["reference"]
+        out["reference_window"] = ref["window"]
+        out["one_gpu_timesteps_per_s"] = ref["timesteps_per_s"]
+        if ref["timesteps_per_s"] and list(ref["window"]) == [d.get("warmup"), d.get("steps"), d.get("windows", 1)]:
+            if weak:
+                out["weak_efficiency_vs_1gpu"] = round(d["ticks_per_s"] / ref["timesteps_per_s"], 4)
+            else:
+                out["speedup_vs_1gpu"] = round(d["ticks_per_s"] / ref["timesteps_per_s"], 3)
     return out
 
 
@@ -466,9 +523,10 @@ def run_c_host(sph, args):
     exchange and rebuild-word reduction over RCCL, no torch in the loop).  Started here as N ranks, or — under torchrun
     — as the one rank this process stands for (the ncclUniqueId then travels through a file named after the job).
     The line's `value` is the WEAK-scaling run (2 000 000 particles per GPU: the cfg2 -> cfg3 family); beside it, under
-    `scaling_detail`, the STRONG-scaling run north_star asks for (cfg4: 32 000 000 particles under the scripted tilt, fixed, over the
-    N ranks, with its speed-up against the N = 1 figure this host's N = 1 run cached), and both once more over the peer
-    transport (guarded: own process group, time limit).
+    `scaling_detail`, the STRONG-scaling runs north_star asks for — cfg4 (32 000 000 particles under the scripted tilt, fixed) over
+    the N ranks, once at rest (steps 50-650) and once developed (steps 2000-2600), each with its speed-up against the one-GPU rate
+    on the SAME window (STRONG_LEGS; cached by this host's N = 1 run, else measured by rank 0 after the multi-rank legs) — and
+    all of it once more over the peer transport (guarded: own process group, time limit).
     --transport host: the same step loop with POSIX shared memory between the ranks (they may share a device: a rehearsal of
     the N-rank code path on fewer GPUs, not a measurement of xGMI).  --transport auto: rccl, and if that run fails the peer
     run becomes the line's value (said so in `transport_used`); without it a failing transport fails the bench."""
@@ -484,12 +542,11 @@ def run_c_host(sph, args):
     if under_launcher and transport != "rccl" and rank != 0:
         return          # (the shared-memory and peer transports start their own ranks: one launcher only)
     n_ranks = world or args.gpus
-    n1 = cached_n1()
 
-    def launch(scene_, steps, warmup, tr, tilt, tag):
+    def launch(scene_, steps, warmup, tr, tilt, tag, windows=1):
         if under_launcher and tr == "rccl":
-            return c_host_run(host, scene_, steps, warmup, tr, tilt, (world, rank), tag)
-        return _own_ranks(host, scene_, steps, warmup, tr, tilt, n_ranks)
+            return c_host_run(host, scene_, steps, warmup, tr, tilt, (world, rank), tag, windows=windows)
+        return _own_ranks(host, scene_, steps, warmup, tr, tilt, n_ranks, windows=windows)
 
     rc, d = launch(scene, args.steps, args.warmup, transport, args.workload == "cfg4", "weak")
     fallback = None
@@ -506,16 +563,34 @@ def run_c_host(sph, args):
             log("bench.py: the peer transport did not complete either:", fallback)
             sys.exit(rc or 1)
         d, transport = fallback["raw"], "peer"
-    # the strong-scaling leg (every rank of a launcher takes part; rank 0 reports)
-    strong = None
-    if scene == "dam" and not args.no_also and n_ranks > 1 and not fallback:
-        rc2, d2 = launch("cfg4", 200, 50, transport, True, "strong")
-        if rc2 == 0 and d2 is not None:
-            strong = leg_summary(d2, n_ranks, n1.get("cfg4"))
-        elif rank == 0:
-            strong = {"status": "failed (exit %d)" % rc2}
+    # the strong-scaling legs (every rank of a launcher takes part; rank 0 reports)
+    strong_raw = {}
+    do_strong = scene == "dam" and not args.no_also and n_ranks > 1 and not fallback
+    if do_strong:
+        for name, (key, wu, st_, wn) in STRONG_LEGS.items():
+            rc2, d2 = launch("cfg4", st_, wu, transport, True, "strong_" + name, windows=wn)
+            strong_raw[name] = d2 if rc2 == 0 and d2 is not None else {"status": "failed (exit %d)" % rc2}
     if rank != 0:
         return
+    peer_raw = {}
+    if transport == "rccl" and n_ranks > 1 and not args.no_also:      # the guarded second leg of everything, before rank 0 takes the GPU for the references
+        peer_raw["weak"] = peer_leg(host, scene, n_ranks, args.steps, args.warmup, args.workload == "cfg4")
+        if scene == "dam":
+            for name, (key, wu, st_, wn) in STRONG_LEGS.items():
+                peer_raw[name] = peer_leg(host, "cfg4", n_ranks, st_, wu, True, windows=wn)
+    # The one-GPU references, each on the window of its leg: from the N = 1 run's cache when the windows agree, else measured now
+    # (the multi-rank legs are over, device 0 is free).  A one-slab run (the slab path's own overhead) has nothing to scale against.
+    refs = {}
+    if n_ranks > 1:
+        if scene == "dam":
+            refs["weak"] = one_gpu_reference(sph, "cfg2_window", args.warmup, args.steps, 1)
+        if do_strong or peer_raw:
+            for name, (key, wu, st_, wn) in STRONG_LEGS.items():
+                if "ticks_per_s" in (strong_raw.get(name) or {}) or (peer_raw.get(name) or {}).get("status") == "ok":
+                    refs[name] = one_gpu_reference(sph, key, wu, st_, wn)
+    strong = None
+    if do_strong:
+        strong = {name: (leg_summary(r, n_ranks, refs.get(name)) if "ticks_per_s" in r else r) for name, r in strong_raw.items()}
     n_total, tps = d["n_fluid"], d["ticks_per_s"]
     step_gbs = sph.STEP_ALGO_BYTES * n_total * tps / 1e9 / n_ranks
     # the dominant kernel (the force pass, which also integrates) of rank 0's slab against the HBM roofline of ITS GPU:
@@ -525,7 +600,7 @@ def run_c_host(sph, args):
     how = {"rccl": ("ncclSend/ncclRecv pair", "4-byte ncclAllReduce(max)"),
            "host": ("shared-memory mailbox (REHEARSAL transport: the ranks may share a GPU)", "host max-reduction"),
            "peer": ("store into the neighbours' hipIpc-mapped memory (no collective library)", "exchange of flag words")}[transport]
-    weak = leg_summary(d, n_ranks, n1.get("cfg2_window") if scene == "dam" else None, weak=True)
+    weak = leg_summary(d, n_ranks, refs.get("weak"), weak=True)
     out = {
         "metric": "SPH Mparticle-steps/sec (N_fluid x timesteps/sec / 1e6)",
         "value": round(d["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s", "timesteps_per_s": round(tps, 2),
@@ -546,28 +621,31 @@ def run_c_host(sph, args):
                      "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
                      "step_unit": "GB/s per GPU (whole step, 152 B per particle-step)"},
         "per_rank": d.get("per_rank"), "breakdown_steps": d.get("breakdown_steps"), "halo_buffer_bytes": d.get("halo_buffer_bytes"),
-        # weak: the line's own run (2 000 000 particles per GPU), strong: cfg4 (32 000 000 particles, fixed) over the same ranks
+        # weak: the line's own run (2 000 000 particles per GPU); strong: cfg4 (32 000 000 particles, fixed) over the same ranks,
+        # at rest and developed, each against the one-GPU rate on its own window
         "scaling_detail": {"weak": weak, "strong": strong},
         "cpu_baseline": cached_cpu_baseline(),      # measured by the N = 1 run on this host (None if there was none)
     }
     if fallback:
         out["transport_used"] = "peer (--transport auto: the RCCL run of this bench did not complete: exit %d)" % rc
-    if transport == "rccl" and n_ranks > 1 and not args.no_also:
-        leg = peer_leg(host, scene, n_ranks, args.steps, args.warmup, args.workload == "cfg4")
+    if peer_raw:
+        leg = peer_raw["weak"]
         raw = leg.pop("raw", None)
         out["peer_transport"] = leg
         if raw is not None:
-            out["peer_transport"]["weak"] = leg_summary(raw, n_ranks, n1.get("cfg2_window") if scene == "dam" else None, weak=True)
+            out["peer_transport"]["weak"] = leg_summary(raw, n_ranks, refs.get("weak"), weak=True)
         if scene == "dam":
-            leg2 = peer_leg(host, "cfg4", n_ranks, 200, 50, True)
-            raw2 = leg2.pop("raw", None)
-            out["peer_transport"]["strong"] = leg_summary(raw2, n_ranks, n1.get("cfg4")) if raw2 is not None else leg2
+            out["peer_transport"]["strong"] = {}
+            for name in STRONG_LEGS:
+                leg2 = peer_raw[name]
+                raw2 = leg2.pop("raw", None)
+                out["peer_transport"]["strong"][name] = leg_summary(raw2, n_ranks, refs.get(name)) if raw2 is not None else leg2
     emit(out)
 
 
-def _own_ranks(host, scene, steps, warmup, transport, tilt, n_ranks):
+def _own_ranks(host, scene, steps, warmup, transport, tilt, n_ranks, windows=1):
     """the C host started as its own launcher (it forks its ranks before anything touches a GPU)"""
-    cmd = c_host_cmd(host, scene, steps, warmup, transport, tilt) + ["--ranks", str(n_ranks)]
+    cmd = c_host_cmd(host, scene, steps, warmup, transport, tilt, windows=windows) + ["--ranks", str(n_ranks)]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -577,14 +655,14 @@ def _own_ranks(host, scene, steps, warmup, transport, tilt, n_ranks):
     return r.returncode, (json.loads(lines[-1]) if lines else None)
 
 
-def peer_leg(host, scene, world, steps, warmup, tilt):
+def peer_leg(host, scene, world, steps, warmup, tilt, windows=1):
     """After the RCCL run (whose numbers are the line's `value`): the same workload once more with --transport peer — the
     step's traffic as stores into hipIpc-mapped peer memory and flag words, three small kernels instead of RCCL's
     all-reduce and send / receive — started by the C host's own launcher, in its own process group, under a time limit.
     A one-GPU pool cannot exercise that transport between GPUs; this leg is how it gets its first run over xGMI without
     putting the headline at risk.  Whatever happens here is reported, never raised."""
     import signal
-    cmd = c_host_cmd(host, scene, steps, warmup, "peer", tilt) + ["--ranks", str(world)]
+    cmd = c_host_cmd(host, scene, steps, warmup, "peer", tilt, windows=windows) + ["--ranks", str(world)]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -691,11 +769,11 @@ def main():
                              "cfg2_at_rest" if args.warmup + args.steps <= 100 else None),
     }
 
-    def also_entry(label, r, traffic_key):
+    def also_entry(label, r, traffic_key, cache_key=None):
         """one secondary measurement in SURVEY.md 8(d)'s protocol: warm-up, then the MEDIAN of several windows — whatever
         --steps says (the headline above is exactly --steps steps after --warmup)"""
         rf = roofline(sph, r, traffic_key)
-        return {"workload": label, "protocol": "8d",
+        return {"workload": label, "protocol": "8d", "cache_key": cache_key, "window": [r["warmup"], r["window_steps"], r["windows"]],
                 "protocol_detail": "%d warm-up steps, median of %d windows of %d steps" % (r["warmup"], r["windows"], r["window_steps"]),
                 "value": round(r["mparticle_steps_per_s"], 2), "unit": "Mparticle-steps/s",
                 "timesteps_per_s": round(r["steps_per_s"], 2), "ms_per_step": round(r["ms_per_step"], 5),
@@ -723,7 +801,7 @@ def main():
         # the headline scene itself, in the protocol: 200 warm-up steps, 5 windows of 1000
         r = run_single(sph, "cfg2", 1000, 200, skin=args.skin, windows=5)
         log("also:", json.dumps(r))
-        out["also"].append(also_entry("cfg2: %d fluid + %d boundary, dam break, box 1200 x 60 m" % (r["n_fluid"], r["n_boundary"]), r, "cfg2"))
+        out["also"].append(also_entry("cfg2: %d fluid + %d boundary, dam break, box 1200 x 60 m" % (r["n_fluid"], r["n_boundary"]), r, "cfg2", "cfg2_8d"))
         # the figure to anchor on: the same scene in SURVEY 8(d)'s protocol (the headline above is whatever window --steps /
         # --warmup ask for: the driver's 20 steps after 5 are a fluid still at rest)
         e = out["also"][-1]
@@ -741,31 +819,30 @@ def main():
         out["also"].append(also_entry("cfg2, developed flow: steps 4000-9000 of the same run", r, "cfg2_developed"))
         # cfg4 as BASELINE.json states it, on ONE GPU: 32 000 000 particles (6.8 GB of device memory: the HBM-resident
         # point, nothing fits the 256 MiB Infinity Cache) under the scripted tilt trace; 3 windows of 200 steps
-        r = run_single(sph, "cfg4", 200, 50, profile_steps=5, skin=args.skin, tilt=True, windows=3)
+        r = run_single(sph, "cfg4", STRONG_LEGS["at_rest"][2], STRONG_LEGS["at_rest"][1], profile_steps=5, skin=args.skin, tilt=True, windows=STRONG_LEGS["at_rest"][3])
         log("also:", json.dumps(r))
         out["also"].append(also_entry("cfg4 on one GPU: %d fluid + %d boundary, box 2400.6 x 150 m, scripted tilt gravity"
-                                      % (r["n_fluid"], r["n_boundary"]), r, "cfg4"))
+                                      % (r["n_fluid"], r["n_boundary"]), r, "cfg4", "cfg4_at_rest" if args.skin is None else None))
         # ... and the same tank once the un-compressed lattice has fallen onto the floor (75 m of water: |v| to 60 m/s at the
         # bounce): steps 2000 - 2600.  The HBM-resident DEVELOPED point: nothing fits the Infinity Cache and the lists are rebuilt
-        r = run_single(sph, "cfg4", 200, 2000, profile_steps=5, skin=args.skin, tilt=True, windows=3)
+        r = run_single(sph, "cfg4", 200, 2000, profile_steps=5, skin=args.skin, tilt=True, windows=3)      # (= STRONG_LEGS["developed"] by default)
         log("also:", json.dumps(r))
-        out["also"].append(also_entry("cfg4 on one GPU, developed flow: steps 2000-2600 of the same run", r, "cfg4_developed"))
-    if out.get("also"):      # the N > 1 runs of this host quote these (weak efficiency, strong speed-up)
-        try:
-            ref = {"cfg2_window": out["timesteps_per_s"], "cfg2_window_steps": [args.warmup, args.steps]}
-            for e in out["also"]:
-                if e["workload"].startswith("cfg2:"):
-                    ref["cfg2"] = e["timesteps_per_s"]
-                if e["workload"].startswith("cfg4"):
-                    ref["cfg4"] = e["timesteps_per_s"]
-            with open(N1_CACHE, "w") as fh:
-                json.dump(ref, fh)
-        except OSError:
-            pass
+        out["also"].append(also_entry("cfg4 on one GPU, developed flow: steps 2000-2600 of the same run", r, "cfg4_developed",
+                                      "cfg4_developed" if args.skin is None else None))
+    if out.get("also") and args.skin is None and not args.load_state and not args.lib:
+        # the N > 1 runs of this host quote these (weak efficiency, strong speed-ups): by leg, each with its window; only what the
+        # library's defaults measured (a fixed skin, a checkpoint or another build are A/B runs)
+        legs = {"cfg2_window": n1_leg(out["timesteps_per_s"], args.warmup, args.steps, 1)}
+        for e in out["also"]:
+            if e.get("cache_key"):
+                legs[e["cache_key"]] = n1_leg(e["timesteps_per_s"], *e["window"])
+        write_n1_cache(legs)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sph, args.workload)
-        if out["cpu_baseline"]:
-            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if out["cpu_baseline"]:      # the sustained figure when there is one (SURVEY 8d's protocol), not whatever window --steps names
+            gpu = out["sustained"]["value"] if out.get("sustained") else out["value"]
+            out["gpu_over_cpu"] = round(gpu / out["cpu_baseline"]["value"], 1)
+            out["gpu_over_cpu_basis"] = "sustained" if out.get("sustained") else "the headline window"
     emit(out)
 
 

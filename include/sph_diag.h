@@ -27,7 +27,14 @@ enum {
     SPH_K_DENSITY_EOS    = 5,  /* :263-289 + :294-301                            */
     SPH_K_FORCE_KICK     = 6,  /* :303-373 + :637-640                            */
     SPH_K_HALO           = 7,  /* end-of-step marker (slab mode: halo pack/ingest) */
-    SPH_K_COUNT          = 8
+    SPH_K_COUNT          = 8,
+    /* sph_time_kernel only: the density launch as sph_step issues it on a single-GPU context — SPECULATIVE, with the check and
+     * verify jobs of the rebuild criterion as extra workgroups of the same launch (see "neighbour-structure reuse" in sph.h) —
+     * followed by a one-thread launch that does for those jobs what the step's gate does when nothing is rebuilt (completion
+     * count, queue length and rebuild word back to where they were): the figure to hold against the profiler's
+     * k_density_list<1, 0, true>, a launch boundary included.  SPH_K_DENSITY_EOS times the plain pass (the tiles alone).
+     * SPH_E_STATE on contexts whose step does not launch it (slabs, the direct variant, contexts that share their device). */
+    SPH_K_DENSITY_SPEC   = 9
 };
 typedef struct sph_kernel_times {
     float ms[SPH_K_COUNT];     /* mean device time per step of each kernel, HIP events on the context's stream */
@@ -40,7 +47,7 @@ typedef struct sph_kernel_times {
 /* run nsteps steps eagerly with HIP events around every kernel (same kernels as sph_step) */
 int  sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_times *out);
 /* mean device time [ms] of `reps` back-to-back launches of ONE per-step kernel on the live state, between two HIP
- * events on the context's stream.  Only the idempotent kernels (SPH_K_DENSITY_EOS, SPH_K_FORCE_KICK: same
+ * events on the context's stream.  Only the idempotent kernels (SPH_K_DENSITY_EOS, SPH_K_DENSITY_SPEC, SPH_K_FORCE_KICK: same
  * inputs -> same outputs, nothing they read is overwritten) can be timed this way; others give SPH_E_ARG.
  * SPH_K_FORCE_KICK re-does the kick of the last step: valid only after at least one sph_step since creation / upload /
  * sph_eval_accel — SPH_E_STATE otherwise: the velocities would be kicked a second time.  SPH_K_BUILD_LIST (single-GPU

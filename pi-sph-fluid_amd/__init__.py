@@ -519,9 +519,11 @@ class Context:
         return d
 
     def time_kernel(self, name, reps=20):
-        """mean ms per launch of an idempotent kernel ('density_eos' or 'force_kick'), back-to-back launches."""
+        """mean ms per launch of an idempotent kernel ('density_eos', 'force_kick', 'build_list'; 'density_spec' = the density
+        launch as sph_step issues it, with the criterion's jobs, + a one-thread reset launch), back-to-back launches."""
         ms = C.c_float()
-        self._chk(self.L.sph_time_kernel(self.h, KERNEL_NAMES.index(name), reps, C.byref(ms)))
+        kid = 9 if name == "density_spec" else KERNEL_NAMES.index(name)      # SPH_K_DENSITY_SPEC (include/sph_diag.h)
+        self._chk(self.L.sph_time_kernel(self.h, kid, reps, C.byref(ms)))
         return ms.value
 
     def set_stream(self, hip_stream):

@@ -675,6 +675,11 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
         drop_graph(ctx);
         ctx->rebuild_wgs = 0;
     }
+    // No step, no new gravity: the vector on the device belongs to the last force pass until the next one runs — the
+    // acceleration of the last step is recomputed from it on demand (refresh_acc), so a host that polls its gravity source
+    // with sph_step(ctx, g_new, 0) and then reads back must still get a(g_old).  (With nsteps > 0 nothing stale can be read
+    // afterwards: whenever the look-ahead is dropped — uploads, variant change — the acceleration was refreshed first.)
+    if (nsteps == 0) return SPH_OK;
     launch_set_gravity(ctx->stream, ctx->a, gx, gy);
     int s = 0;
     while (s < nsteps) {
@@ -1061,8 +1066,10 @@ int sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_t
 
 int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     if (!ctx || !ctx->stream || !ms || reps <= 0) return SPH_E_ARG;
-    if (kernel != SPH_K_DENSITY_EOS && kernel != SPH_K_FORCE_KICK && kernel != SPH_K_BUILD_LIST)
+    if (kernel != SPH_K_DENSITY_EOS && kernel != SPH_K_FORCE_KICK && kernel != SPH_K_BUILD_LIST && kernel != SPH_K_DENSITY_SPEC)
         return fail(ctx, SPH_E_ARG, "sph_time_kernel: kernel is not idempotent");
+    if (kernel == SPH_K_DENSITY_SPEC && (!speculative(ctx) || device_shared(ctx)))
+        return fail(ctx, SPH_E_STATE, "sph_time_kernel(SPH_K_DENSITY_SPEC): this context's step does not launch the speculative density pass");
     if (kernel == SPH_K_BUILD_LIST && ctx->slab) return fail(ctx, SPH_E_STATE, "sph_time_kernel(SPH_K_BUILD_LIST): not on a slab context");
     // the force pass of the step writes velt = vel + dt/2 a: a repeat of the last step's kick only once a step has
     // kicked vel; before that vel == velt and the launch would kick the velocities a second time
@@ -1072,8 +1079,16 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     // the list build on the sort that is there, with the positions of now: what it leaves is replaced by the next step,
     // which finds the rebuild word raised
     if (kernel == SPH_K_BUILD_LIST) launch_request_rebuild(ctx->stream, ctx->a);
+    // the speculative launch as the step issues it (its criterion jobs read the boxes the last force pass left: whatever they find,
+    // the words they raise are put back after every launch, where the step's gate would clear them or rebuild)
+    const bool verify = ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0;
+    if (kernel == SPH_K_DENSITY_SPEC) launch_spec_reset(ctx->stream, ctx->a, 0);
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int r = 0; r < reps; r++) {
+        if (kernel == SPH_K_DENSITY_SPEC) {
+            launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_ALL, false, true, verify);
+            launch_spec_reset(ctx->stream, ctx->a, r + 1 < reps ? 1 : 2);
+        } else
         if (kernel == SPH_K_BUILD_LIST) launch_build_list(ctx->stream, ctx->c, ctx->a, ctx->cap);
         else if (kernel == SPH_K_DENSITY_EOS) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false);
         else launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);

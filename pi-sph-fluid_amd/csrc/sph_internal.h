@@ -152,7 +152,8 @@ enum {
                             //   1 the verification found a pair missing from the lists, 2 somebody drifted H + skin from its sort
                             //   position (the cap), 3 rest mode: somebody beyond skin/2
     FLAG_CHECK_DONE = 29,   // check jobs of the running density launch that have finished (spec_check_job; k_rebuild clears it)
-    FLAG_COUNT = 30
+    FLAG_SAVED_WORD = 30,   // sph_time_kernel(SPH_K_DENSITY_SPEC): the rebuild word as it was before the timed launches
+    FLAG_COUNT = 31
 };
 // Arrays::dyn
 enum {
@@ -226,6 +227,10 @@ void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const
 void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool deterministic = false);
 // raise the rebuild request: the next step rebuilds the neighbour structure
 void launch_request_rebuild(hipStream_t st, const Arrays &a);
+// measurement (sph_time_kernel): what the gate does for the criterion jobs of a speculative density launch when nothing is
+// rebuilt — their completion count and queue length back to 0.  mode 0: before the timed launches (notes the rebuild word and clears
+// it: a raised word sends the tiles of a speculative pass home), 1: between them, 2: after the last (the word as it was)
+void launch_spec_reset(hipStream_t st, const Arrays &a, int mode);
 // first half kick + drift in place (:615-624; slab mode: the owned range); requests a rebuild when the lists may be stale
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab);
 // slab mode: fill the send buffers — rebuild step: keys + histogram of the owned range into the staging arrays + full

@@ -92,6 +92,15 @@ __global__ void k_set_word(uint32_t *word, uint32_t value) { *word = value; }
 void launch_request_rebuild(hipStream_t st, const Arrays &a) {
     hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, (uint32_t)REBUILD_HOST);
 }
+__global__ void k_spec_reset(uint32_t *flags, uint32_t *vq, uint32_t *rebuild, int mode) {
+    if (mode == 0) flags[FLAG_SAVED_WORD] = *rebuild;      // before the timed launches: note the word (the last force pass may have raised it) ...
+    flags[FLAG_CHECK_DONE] = 0u;
+    if (vq) vq[0] = 0u;
+    *rebuild = mode == 2 ? flags[FLAG_SAVED_WORD] : 0u;    // ... keep it clear while they run (a raised word sends the tiles home), put it back afterwards
+}
+void launch_spec_reset(hipStream_t st, const Arrays &a, int mode) {
+    hipLaunchKernelGGL(k_spec_reset, dim3(1), dim3(1), 0, st, a.flags, a.vq, a.rebuild, mode);
+}
 void launch_set_rebuild(hipStream_t st, const Arrays &a, bool on) {
     hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.rebuild, on ? (uint32_t)REBUILD_HOST : 0u);
     if (!on) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, a.check, 0u);
@@ -220,7 +229,7 @@ DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, ui
 // step with skin s costs about K (1 + s)^2 (the two list walkers: list length ~ area of the cut-off disc) plus R / T(s)
 // (a rebuild every T(s) = T s / s0 steps): minimal where  s^2 (1 + s) = (R / 2K) (s0 / T).  On paper R / 2K is 2.9 on
 // MI355X (a rebuild ~200 us, the part of density + force that scales with the lists ~35 us at s = 0, 2M particles; both
-// scale with the particle count); measured (tests/skin_sweep_gpu.py, variants with 2 / 2.9 / 4 / 5.5 / 8): 4 and above are
+// scale with the particle count); measured (tools/skin_sweep_gpu.py, variants with 2 / 2.9 / 4 / 5.5 / 8): 4 and above are
 // equally good and better than 2.9, hence ADAPT_RATIO = 5.  The next skin is half-way from the old one to that optimum, clamped to [skin_min,
 // skin_max] (the grid is sized for skin_max).  Measured on the 2M-particle dam break with FIXED skins: best 0.15 - 0.19
 // while most of the fluid is at rest, 0.30 in the developed flow.  A rebuild the host asked for says nothing about the

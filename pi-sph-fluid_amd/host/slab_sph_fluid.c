@@ -27,7 +27,7 @@
  * The three differ only in the functions under "transport" below; the step loop is one.
  *
  *   slab_sph_fluid --ranks N [--transport rccl|host|peer] [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--origin X0 Y0]
- *                  [--velocity U V] [--steps K] [--warmup W] [--tilt] [--check] [--deterministic] [--skin F]
+ *                  [--velocity U V] [--steps K] [--warmup W] [--windows N] [--tilt] [--check] [--deterministic] [--skin F]
  *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE]
  *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
@@ -125,8 +125,8 @@ static int comm_barrier(comm *cm) {
 static int comm_allreduce(comm *cm, void *buf, size_t count, int op) {
     const size_t esz = op == 0 ? sizeof(long long) : sizeof(float), bytes = count * esz;
     if (cm->nranks == 1) return 0;
-    if (bytes > cm->coll_bytes) { fprintf(stderr, "[rank %d] collective of %zu bytes exceeds the staging size %zu\n", cm->rank, bytes, cm->coll_bytes); return 1; }
     if (cm->kind == TR_RCCL) {
+        if (bytes > cm->coll_bytes) { fprintf(stderr, "[rank %d] collective of %zu bytes exceeds the staging size %zu\n", cm->rank, bytes, cm->coll_bytes); return 1; }
         HIPCHK(hipMemcpy(cm->d_coll, buf, bytes, hipMemcpyHostToDevice));
         NCCLCHK(ncclAllReduce(cm->d_coll, cm->d_coll, count, op == 0 ? ncclInt64 : ncclFloat32, op == 0 ? ncclSum : ncclMax, cm->nccl, NULL));
         HIPCHK(hipStreamSynchronize(NULL));
@@ -681,7 +681,7 @@ static int rebalance(rank_state *rs, float gx, float gy, double min_gain, int *m
 }
 
 int main(int argc, char **argv) {
-    int nranks = 1, rank = -1, steps = 200, warmup = 50, tilt = 0, check = 0, deterministic = 0, transport = TR_RCCL;
+    int nranks = 1, rank = -1, steps = 200, warmup = 50, windows = 1, tilt = 0, check = 0, deterministic = 0, transport = TR_RCCL;
     int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2, breakdown = 0, halo_capacity = -1;
     float skin = -1;
     const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL;
@@ -701,6 +701,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene_name = argv[++i];
         else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--windows") && i + 1 < argc) windows = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--rebalance-every") && i + 1 < argc) rebalance_every = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--capacity") && i + 1 < argc) capacity = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--halo-capacity") && i + 1 < argc) halo_capacity = atoi(argv[++i]);
@@ -722,7 +723,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--velocity") && i + 2 < argc) { sc.u0 = (float)atof(argv[++i]); sc.v0 = (float)atof(argv[++i]); }
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
-    if (nranks < 1 || steps < 0 || warmup < 0 || rebalance_every < 0) return 2;
+    if (nranks < 1 || steps < 0 || warmup < 0 || rebalance_every < 0 || windows < 1 || windows > 64) return 2;
 
     /* ---- scene and parameters (the launcher needs them too: the size of the shared mailboxes) ---- */
     if (!sc.nx) {
@@ -856,7 +857,15 @@ int main(int argc, char **argv) {
     const int pre_reps = getenv("SPH_BENCH_PRE_REPS") ? atoi(getenv("SPH_BENCH_PRE_REPS")) : 300;
     float last_t = 0, worst_rho_err = 0, worst_speed = 0;
     int rebalanced = 0;
-    for (int s = 0; s < warmup + steps; s++) {
+    double win_t[65];                 /* the clock at the start of every timed window and at the end of the last */
+    int n_win = 0;
+    for (int s = 0; s < warmup + windows * steps; s++) {
+        if (s > warmup && steps > 0 && (s - warmup) % steps == 0) {      /* a window ends, the next begins: every rank, like t0 below */
+            HIPCHK(hipStreamSynchronize(rs.st));
+            HIPCHK(hipStreamSynchronize(rs.xst));
+            CHK(comm_barrier(&rs.cm));
+            win_t[++n_win] = now_s();
+        }
         if (s == warmup) {
             /* the two heavy kernels at the start of the timed region (back-to-back launches on the live state; again at
              * the end: the JSON line reports their mean) — and enough of them that a fresh GPU has reached its running
@@ -871,6 +880,7 @@ int main(int argc, char **argv) {
             HIPCHK(hipStreamSynchronize(rs.xst));
             CHK(comm_barrier(&rs.cm));
             t0 = now_s();
+            win_t[0] = t0;
         }
         CHK(step_once(&rs, gx, gy));
         t += prm.dt;                                                             /* :678 */
@@ -894,7 +904,7 @@ int main(int argc, char **argv) {
             last_reported = now;
         }
         sph_gravity_sample(&grav, t, &gx, &gy);                                  /* 10 Hz hold, :455-461 */
-        if (rebalance_every && (s + 1) % rebalance_every == 0 && s + 1 < warmup + steps) {
+        if (rebalance_every && (s + 1) % rebalance_every == 0 && s + 1 < warmup + windows * steps) {
             int rc = sph_sync(rs.ctx);                                           /* capacity / out-of-domain / NaN so far */
             if (rc) { fprintf(stderr, "[rank %d] sph_sync before re-balancing: %d (%s)\n", rank, rc, sph_last_error(rs.ctx)); return 1; }
             int moved = 0;
@@ -909,7 +919,20 @@ int main(int argc, char **argv) {
     HIPCHK(hipStreamSynchronize(rs.st));
     HIPCHK(hipStreamSynchronize(rs.xst));
     CHK(comm_barrier(&rs.cm));
-    const double elapsed = now_s() - t0;
+    win_t[++n_win] = now_s();
+    if (warmup + windows * steps == 0 || steps == 0) { t0 = win_t[0] = win_t[1] = now_s(); n_win = 1; }
+    /* the run's rate: the MEDIAN window (SURVEY 8d's protocol: `--windows 5 --steps 1000`; one window: exactly --steps timed steps) */
+    double win_rate[64], elapsed = win_t[1] - win_t[0];
+    for (int w = 0; w < n_win; w++) win_rate[w] = steps > 0 && win_t[w + 1] > win_t[w] ? (double)steps / (win_t[w + 1] - win_t[w]) : 0.0;
+    {
+        double sorted[64];
+        for (int w = 0; w < n_win; w++) {
+            int k = w;
+            for (; k > 0 && sorted[k - 1] > win_rate[w]; k--) sorted[k] = sorted[k - 1];
+            sorted[k] = win_rate[w];
+        }
+        if (steps > 0 && sorted[n_win / 2] > 0) elapsed = (double)steps / sorted[n_win / 2];
+    }
     int rc = sph_sync(rs.ctx);                                                   /* capacity / out-of-domain / NaN */
     if (rc) { fprintf(stderr, "[rank %d] sph_sync: %d (%s)\n", rank, rc, sph_last_error(rs.ctx)); return 1; }
 
@@ -993,18 +1016,20 @@ int main(int argc, char **argv) {
     if (rank == 0) {
         const double tps = steps > 0 ? (double)steps / elapsed : 0.0;
         printf("{\"host\": \"slab_sph_fluid (C, %s)\", \"workload\": \"%s%s\", \"n_gpus\": %d, \"n_fluid\": %ld, \"n_boundary\": %ld, "
-               "\"steps\": %d, \"warmup\": %d, \"ticks_per_s\": %.2f, \"mparticle_steps_per_s\": %.2f, \"ms_per_step\": %.5f, "
+               "\"steps\": %d, \"warmup\": %d, \"windows\": %d, \"ticks_per_s\": %.2f, \"mparticle_steps_per_s\": %.2f, \"ms_per_step\": %.5f, "
                "\"neighbour_rebuilds\": %lld, \"rebalanced\": %d, \"max_owned\": %lld, \"max_rho\": %.3f, \"max_speed\": %.3f, "
                "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s, "
                "\"halo_buffer_bytes\": %zu, \"breakdown_steps\": %d, \"per_rank\": [",
                transport == TR_RCCL ? "RCCL" : transport == TR_PEER ? "peer-mapped memory" : "host-staged shared memory", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
-               steps, warmup, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
+               steps, warmup, n_win, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
                n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false", rs.x.halo_bytes, bd_ok ? breakdown : 0);
         for (int r = 0; r < nranks; r++) {
             const float *q = rows + (size_t)r * BDW;
             printf("%s{\"rank\": %d, \"device\": %d, \"ranks_seen\": %d, \"owned\": %.0f, \"local\": %.0f, \"begin_us\": %.1f, \"reduce_us\": %.1f, "
                    "\"pack_us\": %.1f, \"exchange_us\": %.1f, \"end_us\": %.1f}", r ? ", " : "", r, (int)q[7], (int)q[8], q[5], q[6], q[0], q[1], q[2], q[3], q[4]);
         }
+        printf("], \"window_ticks_per_s\": [");
+        for (int w = 0; w < n_win; w++) printf("%s%.2f", w ? ", " : "", win_rate[w]);
         printf("]}\n");
         fflush(stdout);
     }
@@ -1046,7 +1071,7 @@ int main(int argc, char **argv) {
         float hx, hy, t2 = 0;
         sph_gravity_sample(&g2, 0.0f, &hx, &hy);
         SPHCHK(one, sph_create(&one, &prm, loc, (int)n_total, rs.walls, (int)rs.nw, hx, hy, rs.device));
-        for (int s = 0; s < warmup + steps; s++) {
+        for (int s = 0; s < warmup + windows * steps; s++) {
             SPHCHK(one, sph_step(one, hx, hy, 1));
             t2 += prm.dt;
             sph_gravity_sample(&g2, t2, &hx, &hy);
@@ -1055,9 +1080,9 @@ int main(int argc, char **argv) {
         SPHCHK(one, sph_read_particles(one, ref));
         const float dx = fmaxf(max_abs_diff(got, ref, gid, n_total, 0), max_abs_diff(got, ref, gid, n_total, 1));
         const float drho = max_abs_diff(got, ref, gid, n_total, 5);
-        const float tol = 1e-6f * (1.0f + sc.box_w) * (float)(1 + (warmup + steps) / 20);      /* ulps of x, growing with the run */
+        const float tol = 1e-6f * (1.0f + sc.box_w) * (float)(1 + (warmup + windows * steps) / 20);      /* ulps of x, growing with the run */
         printf("check: slab path vs sph_step after %d steps: max|dx| = %.3e m (tolerance %.1e), max|drho| = %.3e -> %s\n",
-               warmup + steps, dx, tol, drho, dx <= tol ? "ok" : "FAILED");
+               warmup + windows * steps, dx, tol, drho, dx <= tol ? "ok" : "FAILED");
         sph_destroy(one);
         free(got); free(gid); free(ref);
         if (!(dx <= tol)) return 1;

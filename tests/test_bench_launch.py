@@ -130,14 +130,60 @@ def test_c_host_two_ranks_over_peer_mapped_memory_through_bench(sph):
     assert bad["status"].startswith("not started")
 
 
+def test_one_gpu_references_are_keyed_by_window(tmp_path, monkeypatch):
+    """The N > 1 line forms a speed-up only between two runs of the SAME window (round-4 verdict: one key `cfg4` held the
+    developed-flow rate and was compared with the at-rest strong leg: 1.83x too high).  The cache is by leg, every entry carries
+    (warm-up, steps per window, windows), an entry of another window — or a cache of the old layout — is not used, and
+    leg_summary refuses to divide by a reference whose window differs from the leg's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cache = tmp_path / "n1.json"
+    monkeypatch.setattr(bench, "N1_CACHE", str(cache))
+    assert bench.cached_n1() == {} and bench.one_gpu_reference(None, "cfg4_at_rest", 50, 200, 3, measure=False) is None
+    bench.write_n1_cache({"cfg4_at_rest": bench.n1_leg(834.0, 50, 200, 3), "cfg4_developed": bench.n1_leg(455.5, 2000, 200, 3),
+                          "cfg2_window": bench.n1_leg(12574.0, 5, 20, 1)})
+    at_rest = bench.one_gpu_reference(None, "cfg4_at_rest", 50, 200, 3, measure=False)
+    assert at_rest["timesteps_per_s"] == 834.0 and at_rest["reference"].startswith("cached") and at_rest["window"] == [50, 200, 3]
+    assert bench.one_gpu_reference(None, "cfg4_developed", 2000, 200, 3, measure=False)["timesteps_per_s"] == 455.5
+    assert bench.one_gpu_reference(None, "cfg4_developed", 50, 200, 3, measure=False) is None        # another window: not this entry
+    assert bench.one_gpu_reference(None, "cfg4_at_rest", 50, 200, 1, measure=False) is None
+    assert bench.one_gpu_reference(None, "cfg2_window", 200, 1000, 1, measure=False) is None
+    # the legs' names are what the N = 1 run caches under
+    assert {v[0] for v in bench.STRONG_LEGS.values()} == {"cfg4_at_rest", "cfg4_developed"}
+    d = {"mparticle_steps_per_s": 1.0, "ticks_per_s": 2502.0, "ms_per_step": 0.4, "workload": "cfg4", "n_fluid": 32000000, "host": "c",
+         "particles_conserved": True, "neighbour_rebuilds": 0, "warmup": 50, "steps": 200, "windows": 3}
+    s = bench.leg_summary(d, 8, at_rest)
+    assert s["speedup_vs_1gpu"] == 3.0 and s["one_gpu_timesteps_per_s"] == 834.0 and s["reference_window"] == s["window"] == [50, 200, 3]
+    wrong = dict(at_rest, window=[2000, 200, 3])
+    assert "speedup_vs_1gpu" not in bench.leg_summary(d, 8, wrong)
+    assert "speedup_vs_1gpu" not in bench.leg_summary(d, 8, None)
+    # a cache written by round 4's bench.py ({"cfg2": .., "cfg4": ..}: no schema) is ignored
+    cache.write_text(json.dumps({"cfg2_window": 12574.0, "cfg2": 9924.0, "cfg4": 455.5}))
+    assert bench.cached_n1() == {}
+
+
 @pytest.mark.gpu
-def test_six_ranks_rehearsal_weak_and_strong_legs(sph):
+def test_six_ranks_rehearsal_weak_and_strong_legs(sph, tmp_path):
     """The N > 1 line as the driver's 8-GPU node will get it, rehearsed on the one GPU of this box: `bench.py --gpus 6` over
     the peer transport (six processes — the most this pool lets touch one GPU at a time; the multi-GPU node runs eight), the
     weak-scaling run as the line's value and, under scaling_detail, the STRONG leg: cfg4 (32 000 000 particles under the tilt
     trace) cut into the same six slabs, with the per-rank breakdown of a step (device, ranks seen, particles, begin / reduce /
     pack / exchange / end) in both.  Small step counts: this is a rehearsal of the code path, not a measurement."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    # The N = 1 run of this host first (the driver's command, without the CPU leg): it caches the one-GPU rates by leg and window.
+    # The rehearsal's developed strong leg is cut short (300 + 3 x 40 steps): its window is then NOT the cached one.
+    cache = str(tmp_path / "n1.json")
+    env.update(SPH_BENCH_N1_CACHE=cache, SPH_BENCH_STRONG_DEVELOPED="300,40,3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu"], capture_output=True,
+                       timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    n1 = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    legs = json.load(open(cache))["legs"]
+    also = {e["cache_key"]: e for e in n1["also"] if e.get("cache_key")}
+    assert legs["cfg4_at_rest"] == {"timesteps_per_s": also["cfg4_at_rest"]["timesteps_per_s"], "warmup": 50, "steps": 200, "windows": 3}
+    assert legs["cfg4_developed"]["timesteps_per_s"] == also["cfg4_developed"]["timesteps_per_s"] and legs["cfg4_developed"]["warmup"] == 2000
+    assert legs["cfg4_at_rest"]["timesteps_per_s"] > 1.3 * legs["cfg4_developed"]["timesteps_per_s"]      # (two regimes: what the mix-up cost)
+    assert legs["cfg2_window"]["timesteps_per_s"] == n1["timesteps_per_s"] and legs["cfg2_window"]["warmup"] == 5
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--transport", "peer", "--steps", "12", "--warmup", "4"],
                        capture_output=True, timeout=1100, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -147,7 +193,20 @@ def test_six_ranks_rehearsal_weak_and_strong_legs(sph):
     assert len(pr) == 6 and [q["rank"] for q in pr] == list(range(6)) and all(q["ranks_seen"] == 6 for q in pr)
     assert sum(q["owned"] for q in pr) == 12000000 and out["breakdown_steps"] > 0
     assert all(q["begin_us"] > 0 and q["end_us"] > 0 and q["exchange_us"] > 0 for q in pr), pr
+    weak = out["scaling_detail"]["weak"]
+    assert weak["n_fluid"] == 12000000
+    # the weak leg's window (12 steps after 4) is not the cached headline window (20 after 5): measured in this run
+    assert weak["reference"].startswith("measured in this run") and weak["reference_window"] == [4, 12, 1]
+    assert weak["weak_efficiency_vs_1gpu"] == pytest.approx(weak["timesteps_per_s"] / weak["one_gpu_timesteps_per_s"], rel=1e-3)
     strong = out["scaling_detail"]["strong"]
-    assert strong["n_fluid"] == 32000000 and strong["particles_conserved"] is True and "tilt" in strong["workload"]
-    assert len(strong["per_rank"]) == 6 and sum(q["owned"] for q in strong["per_rank"]) == 32000000
-    assert out["scaling_detail"]["weak"]["n_fluid"] == 12000000
+    for name, st in strong.items():
+        assert st["n_fluid"] == 32000000 and st["particles_conserved"] is True and "tilt" in st["workload"], name
+        assert len(st["per_rank"]) == 6 and sum(q["owned"] for q in st["per_rank"]) == 32000000
+        assert st["reference_window"] == st["window"]
+        assert st["speedup_vs_1gpu"] == pytest.approx(st["timesteps_per_s"] / st["one_gpu_timesteps_per_s"], rel=2e-3)
+    # at rest: the window of the N = 1 run's cfg4 leg -> ITS cached figure (not the developed one: round 4's 1.83x)
+    assert strong["at_rest"]["window"] == [50, 200, 3] and strong["at_rest"]["reference"].startswith("cached")
+    assert strong["at_rest"]["one_gpu_timesteps_per_s"] == legs["cfg4_at_rest"]["timesteps_per_s"]
+    # developed: this run's window differs from the cached one -> rank 0 measured the one-GPU rate itself, on that window
+    assert strong["developed"]["window"] == [300, 40, 3] and strong["developed"]["reference"].startswith("measured in this run")
+    assert strong["developed"]["one_gpu_timesteps_per_s"] != legs["cfg4_developed"]["timesteps_per_s"]

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import B_EOS
+from conftest import B_EOS, fused_step_vs_oracle
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -75,6 +75,12 @@ def test_cfg4_tilt_four_slabs_equal_single_context(sph, orc, oracle):
             del ref, seen
             if k == 300:
                 del out, du, dv
+        # ONE more step of the single context (the fused loop bench.py times at this size), under the next sample of the trace:
+        # the state around it, for the oracle's step on slab 1's range below
+        one_before, one_a_before = ctx.read_particles(), ctx.read_accel()
+        g_next = grav1(0)
+        ctx.step(1, *g_next)
+        one_after, one_a_after = ctx.read_particles(), ctx.read_accel()
     # ---- the oracle on slab 1's range of the developed state (step 2000): owned columns + 2 columns of halo on each side,
     # under the gravity vector the last step was given ----
     replay = sph.GravitySource(sph.GRAVITY_TILT, 9.81)      # (the source holds its value for 0.1 s since ITS last reading, like the
@@ -106,6 +112,17 @@ def test_cfg4_tilt_four_slabs_equal_single_context(sph, orc, oracle):
     assert np.max(err[own]) <= TOL                                                            # G3 (fused force + kick pass)
     for s in slabs:
         s.close()
+    del slabs, runner, out, du, dv, of, odu, odv, sa, err
+    # ---- the fused step 2000 -> 2001 of the single context against ONE oracle step, on the same range (positions and half-kicked
+    # velocities of every particle in it; rho, p, a and the full-step velocity where the neighbourhood is complete: the owned
+    # columns): pi_sph_fluid.c:612-641 at the HBM-resident size ----
+    gc = sph.slab.global_columns(prm, one_before["x"])
+    sel = np.nonzero((gc >= c0 - 2) & (gc < c1 + 2))[0]
+    own = (gc[sel] >= c0) & (gc[sel] < c1)
+    worst = fused_step_vs_oracle(orc, oracle, p, ob, one_before[sel], (one_a_before[0][sel], one_a_before[1][sel]), one_after[sel],
+                                 (one_a_after[0][sel], one_a_after[1][sel]), g_next, dt, own=own, threads=THREADS, tag="cfg4 slab 1 range")
+    print("cfg4 @2000, one fused step / oracle on %d particles (%d with their whole neighbourhood), worst error over tolerance: %s"
+          % (len(sel), int(own.sum()), {k: round(v, 3) for k, v in worst.items()}))
 
 
 def test_cfg4_eight_slabs_equal_single_context(sph):

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import B_EOS, GX, GY
+from conftest import B_EOS, GX, GY, fused_step_vs_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -118,3 +118,46 @@ def test_fullsize_scene_vs_oracle(sph, orc, oracle, name, warm):
         assert np.max(np.hypot(edu - sdu, edv - sdv) / (sa + G)) <= 4e-6      # (two summation orders of ~30 f32 terms)
     print("%s @%d: rebuilds %d, direct tiles %d (live) / %d (after re-bin), max speed %.1f m/s"
           % (name, warm, rebuilds, direct, direct2, float(np.hypot(got["u"], got["v"]).max())))
+
+
+@pytest.mark.parametrize("name,warm", [("cfg1", 7000), ("cfg2", 4000)])
+def test_fullsize_one_fused_step_vs_oracle(sph, orc, oracle, name, warm):
+    """What bench.py times is the fused loop: the force pass (k_force_list<KICK_DRIFT>) also makes the NEXT step's kick 1/2 +
+    drift (pi_sph_fluid.c:615-624) and the second half kick (:637-640), and stores neither the acceleration nor the velocity
+    between steps.  One step of that loop at full size, on the developed state, against ONE oracle step from the same state
+    (round-4 verdict: its integration had met the oracle only through trajectories of <= 14 400 particles): positions,
+    half-kicked and full-step velocities, rho / p / a of the new state, and that sph_read_accel's recomputed a is the a the
+    kernel kicked with (conftest.fused_step_vs_oracle).  Then the same step from an UPLOADED copy of the state (sph_upload_state +
+    sph_upload_accel: the first step after an upload drifts with the stand-alone k_kick_drift, the one after it with the
+    look-ahead again): both against the oracle and against each other."""
+    prm, f, b = _scene(sph, name)
+    p = oracle.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
+    ob = b.view(orc.PARTICLE).copy()
+    oracle.psi(p, ob)
+    dt = float(np.float32(prm.dt))
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.step(warm, GX, GY)
+        before, a_before = ctx.read_particles(), ctx.read_accel()
+        assert np.hypot(before["u"], before["v"]).max() > 5.0
+        ctx.step(1, GX, GY)                                   # consumes the look-ahead of step `warm`'s force pass
+        after, a_after = ctx.read_particles(), ctx.read_accel()
+        w1 = fused_step_vs_oracle(orc, oracle, p, ob, before, a_before, after, a_after, (GX, GY), dt, threads=THREADS, tag=name + " live")
+        ctx.step(1, GX, GY)                                   # ... and once more: a step whose predecessor was read back in between
+        after2, a_after2 = ctx.read_particles(), ctx.read_accel()
+        w2 = fused_step_vs_oracle(orc, oracle, p, ob, after, a_after, after2, a_after2, (GX, GY), dt, threads=THREADS, tag=name + " live + 1")
+    # the checkpoint path: a fresh context, the state uploaded (x, v, rho, p as read, du_dt, dv_dt), two steps
+    with sph.Context(prm, f, b, GX, GY) as ctx:
+        ctx.upload_state(before)
+        ctx.upload_accel(*a_before)
+        ctx.step(1, GX, GY)                                   # stand-alone kick 1/2 + drift (k_kick_drift), then density + fused force
+        up, a_up = ctx.read_particles(), ctx.read_accel()
+        w3 = fused_step_vs_oracle(orc, oracle, p, ob, before, a_before, up, a_up, (GX, GY), dt, threads=THREADS, tag=name + " uploaded")
+        ctx.step(1, GX, GY)
+        up2, a_up2 = ctx.read_particles(), ctx.read_accel()
+        w4 = fused_step_vs_oracle(orc, oracle, p, ob, up, a_up, up2, a_up2, (GX, GY), dt, threads=THREADS, tag=name + " uploaded + 1")
+    # the two routes to step warm + 1 agree: identical positions up to the rounding of one fma against a multiply + add
+    for c in ("x", "y"):
+        assert np.max(np.abs(up[c].astype(np.float64) - after[c].astype(np.float64)) / np.spacing(np.abs(after[c]))) <= 2.0
+    assert np.max(np.abs(up["rho"] - after["rho"]) / after["rho"]) <= 4e-6
+    print("%s @%d one fused step / oracle, worst error over tolerance: live %s | live + 1 %s | uploaded %s | uploaded + 1 %s"
+          % (name, warm, *({k: round(v, 3) for k, v in w.items()} for w in (w1, w2, w3, w4))))

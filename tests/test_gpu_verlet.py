@@ -183,7 +183,7 @@ def test_verification_instead_of_rebuilds(sph, orc):
 def test_skin_controller(sph, orc):
     """the default skin adapts to how long the lists last (adapt_skin, csrc/sph_kernels.hip): particles that cross a
     skin within a few steps drive it up to sph_params.skin, a tank at rest keeps it at skin_min (that the controller also
-    comes back down shows in the long dam-break runs: tests/skin_sweep_gpu.py, tests/soak_gpu.py); the lists stay
+    comes back down shows in the long dam-break runs: tools/skin_sweep_gpu.py, tools/soak_gpu.py); the lists stay
     exact throughout (they are checked against the exact walk)."""
     rng = np.random.default_rng(11)
     box = (0.0, 16.0, 0.0, 16.0)
@@ -287,6 +287,37 @@ def test_acceleration_of_the_fused_step_is_recomputed_on_demand(sph, orc):
             again.step(151, GX, GY)
             du4, dv4 = again.read_accel()
         assert np.array_equal(du3, du4) and np.array_equal(dv3, dv4)
+
+
+def test_gravity_polled_without_a_step_does_not_change_the_last_acceleration(sph, orc):
+    """A tilt-driven host polls its gravity source and may call sph_step(ctx, g_new, 0) before it reads back (round-4 advisor
+    finding): the acceleration of the last step is recomputed on demand from the gravity left on the device, so a call that takes
+    no step must leave that vector alone.  du_dt, dv_dt and the full-step velocity after step(k, g1); step(0, g2) equal those
+    of step(k, g1) bit for bit (deterministic order), and the next step(1, g2) does use g2."""
+    prm, f, b, g = block_scene(sph, orc, None)
+    prm.deterministic = 1
+    g2 = (3.0, -7.5)
+
+    def run(poll):
+        out = []
+        with sph.Context(prm, f, b, GX, GY) as ctx:      # (one context at a time: each keeps the one-launch step)
+            ctx.step(40, GX, GY)
+            if poll:
+                ctx.step(0, *g2)                        # the poll: no step taken
+            out += list(ctx.read_accel())
+            p = ctx.read_particles()
+            out += [p["u"], p["v"]]
+            ctx.step(1, *g2)
+            out += list(ctx.read_accel())
+            if poll:
+                ctx.step(0, GX, GY)
+            ctx.step(1, GX, GY)
+            out.append(ctx.read_particles()["x"])
+        return out
+
+    polled, plain = run(True), run(False)
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(polled, plain))
+    assert not np.array_equal(plain[0], plain[4])      # (the step under g2 did change du_dt)
 
 
 def test_no_viscosity_is_exactly_no_viscous_term(sph, orc):

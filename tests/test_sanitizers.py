@@ -59,3 +59,9 @@ def test_shared_memory_transport_under_tsan():
         assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
         assert "ok" in r.stdout
+    # a rank whose callback fails in front of the barrier: every rank returns an error, nobody is left waiting (the run ENDS)
+    for ranks, bad, step in ((2, 0, 0), (4, 2, 17), (8, 7, 5)):
+        r = subprocess.run([exe, str(ranks), "50", str(bad), str(step)], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66"))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert "ThreadSanitizer" not in r.stderr and "reached every rank" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -1,5 +1,5 @@
 """Manual (not collected): density / force / list-build / whole-rebuild timings of one or more builds of the library on
-cfg2 after a warm-up.  Usage: python tests/kb2_gpu.py [warmup] lib1.so lib2.so ..."""
+cfg2 after a warm-up.  Usage: python tools/kb2_gpu.py [warmup] lib1.so lib2.so ..."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

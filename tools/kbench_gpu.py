@@ -1,7 +1,7 @@
 """Manual kernel timing (not collected by pytest): cfg2 after warm-up, back-to-back launches of the two heavy
 kernels, then the force-kernel ablation builds (SPH_ABLATE bits: 1 = gathers read one address, 2 = no pair
 arithmetic, 4 = no staging) when the measurement library exists (`make -C pi-sph-fluid_amd ablate`: the only build that
-reads $SPH_ABLATE).  Usage: python tests/kbench_gpu.py [warmup_steps] [skin]"""
+reads $SPH_ABLATE).  Usage: python tools/kbench_gpu.py [warmup_steps] [skin]"""
 import importlib
 import os
 import sys

@@ -1,5 +1,5 @@
 """Manual (not collected): steps/s of cfg2 over the windows of SURVEY 8(d) (200 warm-up, 5 x 1000) and of the developed flow
-(steps 4000-9000) for a few skins.  Usage: python tests/skin_sweep_gpu.py 0.10 0.15 0.12:0.30 ...  (a:b = adaptive
+(steps 4000-9000) for a few skins.  Usage: python tools/skin_sweep_gpu.py 0.10 0.15 0.12:0.30 ...  (a:b = adaptive
 between a and b; one number = fixed; "@name" appended: with csrc/libsph_hip_name.so, a `make variant` build)"""
 import importlib, os, sys, time
 import numpy as np
