@@ -197,13 +197,13 @@ def test_six_ranks_rehearsal_weak_and_strong_legs(sph, tmp_path):
     assert weak["n_fluid"] == 12000000
     # the weak leg's window (12 steps after 4) is not the cached headline window (20 after 5): measured in this run
     assert weak["reference"].startswith("measured in this run") and weak["reference_window"] == [4, 12, 1]
-    assert weak["weak_efficiency_vs_1gpu"] == pytest.approx(weak["timesteps_per_s"] / weak["one_gpu_timesteps_per_s"], rel=1e-3)
+    assert weak["weak_efficiency_vs_1gpu"] == pytest.approx(weak["timesteps_per_s"] / weak["one_gpu_timesteps_per_s"], abs=1e-4)
     strong = out["scaling_detail"]["strong"]
     for name, st in strong.items():
         assert st["n_fluid"] == 32000000 and st["particles_conserved"] is True and "tilt" in st["workload"], name
         assert len(st["per_rank"]) == 6 and sum(q["owned"] for q in st["per_rank"]) == 32000000
         assert st["reference_window"] == st["window"]
-        assert st["speedup_vs_1gpu"] == pytest.approx(st["timesteps_per_s"] / st["one_gpu_timesteps_per_s"], rel=2e-3)
+        assert st["speedup_vs_1gpu"] == pytest.approx(st["timesteps_per_s"] / st["one_gpu_timesteps_per_s"], abs=1e-3)
     # at rest: the window of the N = 1 run's cfg4 leg -> ITS cached figure (not the developed one: round 4's 1.83x)
     assert strong["at_rest"]["window"] == [50, 200, 3] and strong["at_rest"]["reference"].startswith("cached")
     assert strong["at_rest"]["one_gpu_timesteps_per_s"] == legs["cfg4_at_rest"]["timesteps_per_s"]
