@@ -131,6 +131,9 @@ int make_consts(const sph_params &p, Consts &c) {
     c.k1 = p.k1;
     c.eps_h2 = (float)((double)p.eps * H * H);                           // :332
     c.visc_c = (float)((double)p.alpha * (double)p.c * H);               // :332, :334
+    c.pair_k4 = sqrtf(sqrtf(c.k1)) * (c.nf * c.inv_w_k2h);               // (f32, the expressions the kernel used to evaluate per wave)
+    c.pair_tq4 = 2.0f * c.inv_h * c.pair_k4;
+    c.rho_scale = 1.0f / (-2.0f * c.visc_c);
     c.m_fluid = p.rho0 * p.vol;                                          // :502
     c.rho0 = p.rho0;
     c.inv_rho0 = 1.0f / p.rho0;

@@ -28,6 +28,11 @@ struct Consts {
     float k1;                // 0.1                   :325
     float eps_h2;            // 0.01 H^2              :332
     float visc_c;            // 0.01 C H  (alpha c h) :332,:334
+    // the list force pass's folded constants (pair_coef_ff, sph_list.inc), evaluated ONCE on the host: as expressions of the fields
+    // above they were two correctly rounded square roots and a division — ~50 vector instructions — at the top of every wave
+    float pair_k4;           // k1^(1/4) nf / W(0.2 H):  (pair_k4 W / nf)^4 = k1 (W / W(0.2H))^4   :325
+    float pair_tq4;          // 2 pair_k4 / H
+    float rho_scale;         // 1 / (-2 alpha c h): the staged densities of a tile are pre-divided (-inf without viscosity: the term is exactly 0)
     // particle / EOS (:294-301, :502)
     float m_fluid;           // RHO_0 V
     float rho0, inv_rho0;

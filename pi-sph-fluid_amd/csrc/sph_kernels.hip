@@ -132,6 +132,34 @@ DEV float group_max(float v) {
     for (int d = BOXG / 2; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
     return v;
 }
+// The displacement box of a whole wave (BOXG == 64): x0 = min, y0 = min, x1 = max, y1 = max over the 64 lanes, valid in EVERY lane.
+// __shfl_xor is ds_bpermute_b32 on this target: the four butterflies above were 24 trips through the LDS pipe plus ~80 vector
+// instructions at the very end of every wave of the force pass (round 5: ~9 % of its instructions).  Here: four DPP steps inside
+// the rows of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: min and max are idempotent, so mirrors do as well as
+// butterflies) — v_min / v_max with a DPP operand, one instruction per step and value — then the four rows through v_readlane.
+// (A DPP operand must not be read within two wait states of the instruction that wrote it and nothing tracks that inside an asm
+// block: the four values are interleaved, so every result is three instructions old when it is read again; one s_nop in front.)
+DEV void wave_box64(float &x0, float &y0, float &x1, float &y1) {
+#define SPH_DPP_STEP(CTRL)                                                                   \
+    "v_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_min_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_max_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_max_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t" SPH_DPP_STEP("quad_perm:[1,0,3,2]") SPH_DPP_STEP("quad_perm:[2,3,0,1]") SPH_DPP_STEP("row_half_mirror")
+                 SPH_DPP_STEP("row_mirror") "s_nop 1"
+                 : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1));
+#undef SPH_DPP_STEP
+#define SPH_ROWS(v, OP)                                                                                                     \
+    OP(OP(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)),                                 \
+          __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16))),                               \
+       OP(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32)),                                \
+          __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 48))))
+    x0 = SPH_ROWS(x0, fminf);
+    y0 = SPH_ROWS(y0, fminf);
+    x1 = SPH_ROWS(x1, fmaxf);
+    y1 = SPH_ROWS(y1, fmaxf);
+#undef SPH_ROWS
+}
 // all 64 lanes of the wave must call this (live = the lane holds a particle this rank integrates: in slab mode the
 // boxes cover the owned particles only); group = the wave's box group (tile * 4 + wave of the tile: sph_list.inc).  A group
 // without a live lane leaves an empty box (zero displacement): in slab mode k_check may look at it (see there).
@@ -147,8 +175,12 @@ DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group
     const bool over = live && !(fmaf(rx, rx, ry * ry) <= dyn[DYN_LIM2]);      // true for NaN too
     const bool capped = live && !(d2 <= c.cap2);
     const float inf = __builtin_huge_valf();
-    const float x0 = group_min(live ? ux : inf), y0 = group_min(live ? uy : inf);
-    const float x1 = group_max(live ? ux : -inf), y1 = group_max(live ? uy : -inf);
+    float x0 = live ? ux : inf, y0 = live ? uy : inf, x1 = live ? ux : -inf, y1 = live ? uy : -inf;
+    if (BOXG == 64) {
+        wave_box64(x0, y0, x1, y1);
+    } else {
+        x0 = group_min(x0); y0 = group_min(y0); x1 = group_max(x1); y1 = group_max(y1);
+    }
     const unsigned long long any_over = __ballot(over), any_cap = __ballot(capped);
     const unsigned long long gmask = (BOXG == 64 ? ~0ull : ((1ull << (BOXG & 63)) - 1ull)) << (threadIdx.x & 63 & ~(BOXG - 1));
     const unsigned long long any_live = __ballot(live) & gmask;      // (the live lanes of THIS group)
@@ -874,12 +906,14 @@ void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap, b
 
 // ------------------------------------------------------------------------------------------
 // Tait EOS, clamped at zero (:294-301): p = max(0, B((rho/rho0)^7 - 1)); also p/rho^2 for the force pass.
+// (rho / rho0 as a multiplication by 1 / rho0 and p / rho^2 through v_rcp_f32 — one ulp each, 1e-7 of gates that are 1e-5 wide —
+// instead of two IEEE divisions: ~25 of the density pass's ~450 vector instructions per wave)
 DEV void eos(const Consts &c, float rho, float &p, float &p_over_rho2) {
-    float r = rho / c.rho0;
+    float r = rho * c.inv_rho0;
     float r2 = r * r, r4 = r2 * r2;
     float r7 = r4 * r2 * r;
     p = fmaxf(c.B * (r7 - 1.0f), 0.0f);
-    p_over_rho2 = p / (rho * rho);
+    p_over_rho2 = p * __builtin_amdgcn_rcpf(rho * rho);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -946,7 +980,7 @@ __global__ __launch_bounds__(BLK) void k_eos(Consts c, float2 *__restrict__ rp, 
     if (i >= (int)dn[0]) return;
     float rho = rp[i].x;
     if (FROM_PRS) {
-        rp[i].y = prs[i] / (rho * rho);
+        rp[i].y = prs[i] * __builtin_amdgcn_rcpf(rho * rho);      // (as eos())
     } else {
         float p, pr2;
         eos(c, rho, p, pr2);
@@ -1366,7 +1400,7 @@ __global__ __launch_bounds__(BLK) void k_gather_rho_p(const sph_particle *__rest
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
     sph_particle q = in[id[i]];
-    rp[i] = make_float2(q.rho, q.p / (q.rho * q.rho));
+    rp[i] = make_float2(q.rho, q.p * __builtin_amdgcn_rcpf(q.rho * q.rho));      // (as eos())
     prs[i] = q.p;
 }
 
