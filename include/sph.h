@@ -200,22 +200,29 @@ int  sph_get_rebuild_launches(const sph_ctx *ctx);      /* 1: one launch, 0: one
 /* ---- multi-GPU: x-slab domain decomposition, one process per GPU ----
  * The reference has no distributed path; this is the sharding of its particle loops (:272, :311) by cell column.
  * A slab owns the cell columns [col_begin, col_end) of the device grid (sph_device_cell) and keeps 2 ghost columns
- * per side.  One halo exchange per step, as fixed-capacity buffers: uint32 header[4] = {count, kind, 0, 0}, then
- *   kind 0 (a step that rebuilds the neighbour structure): records of 5 words {x, y, u, v, id} — every particle now
- *          inside the neighbour's reach (this slab's 2 outermost owned columns + anything that migrated across since
- *          the last rebuild); ownership follows position: after the sort a slab owns whatever lies in its columns;
- *   kind 1 (any other step): records of 4 words {x, y, u, v} — the 2 outermost owned columns in array order, which
- *          is the order of the neighbour's ghost columns (interface cells are kept sorted by particle id).
+ * per side.  One halo exchange per step, as fixed-capacity buffers: uint32 header[4] = {update count, update step, record
+ * count, record step}, then ONE payload that holds either
+ *   records (a step that rebuilds the neighbour structure): 5 words {x, y, u, v, id} each — every particle now inside the
+ *          neighbour's reach (this slab's 2 outermost owned columns + anything that migrated across since the last rebuild);
+ *          ownership follows position: after the sort a slab owns whatever lies in its columns.  Appended by
+ *          sph_slab_step_pack; header words 2 and 3 (zeroed at the start of every step) count them and name the step;
+ *   an update (any other step): 4 words {x, y, u, v} per particle of the 2 outermost owned columns in array order, which is
+ *          the order of the neighbour's ghost columns (interface cells are kept sorted by particle id).  Written — header
+ *          words 0 and 1 included — by the kernel that drifted the particles: the force pass of the step BEFORE (it has the
+ *          next step's positions and velocities in registers; round 5), after creation the stand-alone kick / drift.
+ *          sph_slab_step_pack has nothing to do on such a step.
+ * The receiver checks count and step of what it consumes (SPH_E_STATE: neighbouring slabs out of step).
  * All slabs must rebuild in the same step, so the rebuild request is ONE 32-bit word per slab that the host
  * MAX-reduces over all ranks each step (RCCL all-reduce on the device word, or any other transport):
  *     sph_slab_step_begin()   kick 1/2 + drift of the owned particles; raises the word when lists may be stale (:615-624)
  *     -- reduce the word over all ranks --
- *     sph_slab_step_pack()    fills the send buffers (kind 0 or 1 according to the word)
+ *     sph_slab_step_pack()    a rebuild step: fills the send buffers with records (any other step: the update is there already)
  *     -- move send_right -> right neighbour's recv_left, send_left -> left neighbour's recv_right --
  *     sph_slab_step_overlap() optional, while the buffers move: density of the tiles that stage no ghost particle
  *                             (or sph_slab_step_overlap_on(): the same on a stream of the host's, from right after
  *                             sph_slab_step_begin — beside the reduction of the word too)
- *     sph_slab_step_end()     ingest + sort + lists (kind 0) or ghost update (kind 1), density + EOS + force + kick (:626-640) */
+ *     sph_slab_step_end()     ingest + sort + lists (records) or ghost update, density + EOS + force + kick (:626-640);
+ *                             the force pass leaves the NEXT step's update message in the send buffers */
 typedef struct sph_slab_desc {
     int col_begin, col_end;      /* owned global cell columns [begin, end), at least 4 */
     int has_left, has_right;     /* a neighbouring slab exists */
@@ -246,7 +253,8 @@ int  sph_slab_flag_get(sph_ctx *ctx, uint32_t *value);
 int  sph_slab_flag_set(sph_ctx *ctx, uint32_t value);
 /* device addresses and byte size of the four halo buffers (library-owned unless replaced below) */
 int  sph_slab_buffers(sph_ctx *ctx, void **send_left, void **send_right, void **recv_left, void **recv_right, size_t *bytes);
-/* adopt device buffers of the host framework (e.g. torch tensors handed to RCCL); each >= the size above */
+/* adopt device buffers of the host framework (e.g. torch tensors handed to RCCL); each >= the size above.  Between steps only;
+ * what the send buffers hold (the next step's update message) moves along */
 int  sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void *recv_left, void *recv_right, size_t bytes);
 /* host-staged transport (tests, non-RCCL hosts): side 0 = left, 1 = right */
 int  sph_slab_copy_out(sph_ctx *ctx, int side, void *host_bytes);
@@ -270,6 +278,32 @@ int  sph_slab_copy_in(sph_ctx *ctx, int side, const void *host_bytes);
 int  sph_slab_peer_reduce(sph_ctx *ctx, void *const *slots_of_rank, int me, int n_ranks, uint32_t tag);
 int  sph_slab_peer_push(sph_ctx *ctx, void *left_recv_right, void *left_flag, void *right_recv_left, void *right_flag, uint32_t tag);
 int  sph_slab_peer_wait(sph_ctx *ctx, const void *flag_from_left, const void *flag_from_right, uint32_t tag);
+/* ---- the lean slab step (round 5): ONE call, FOUR kernels, nothing of the exchange as a launch of its own ----
+ *     head      k_check's work (count the step, this step's gravity, the boxes when somebody is beyond skin/2) and, with links,
+ *               the push of this step's update message (the last force pass left it in the send buffers) into the neighbours'
+ *               receive buffers + their arrival flags, and the MAX of the rebuild word over the ranks (slot arrays, as above)
+ *     update /  a step that does not rebuild: waits for the neighbours' flags (with links), updates the ghosts.  A rebuild step:
+ *     rebuild   the pack (keys + histogram of the owned range, records for the neighbours), with links the records pushed to the
+ *               neighbours and theirs awaited between two grid barriers, ingest, scan, scatter, canonical order, lists — ONE
+ *               launch: the context must have been given its device (sph_set_rebuild_launches(ctx, 1)) — SPH_E_STATE otherwise
+ *     density   rho + EOS of every tile
+ *     force     a, kick, the NEXT step's kick 1/2 + drift — and its update message into the send buffers
+ * (pi_sph_fluid.c:612-641; the three-call step above is six to eight launches.)  Without links (sph_slab_set_peer_links never
+ * called, or NULL): a slab without neighbours.  The links name memory of the other ranks as mapped into this process
+ * (hipIpcOpenMemHandle: the peer-mapped transport above); every rank's block holds TWO receive buffers per side — the message
+ * of step t goes to parity t & 1: a neighbour may push step t + 1 while this rank still reads step t — one arrival flag per side
+ * (tag 2 t for the update of step t, 2 t + 1 for the records of a rebuild step t) and the slot array of the word exchange.
+ * All waits are bounded (SPH_E_STATE at the next call that reads the flags). */
+typedef struct sph_peer_links {
+    int   me, n_ranks;
+    void *slots_of_rank[SPH_PEER_MAX_RANKS];   /* every rank's slot array uint32[2][SPH_PEER_MAX_RANKS] (entry `me`: this rank's own) */
+    void *left_recv[2],  *left_flag;            /* the LEFT neighbour's receive buffers for what comes from ITS right (parity 0, 1) and that flag; NULL: no neighbour */
+    void *right_recv[2], *right_flag;           /* the RIGHT neighbour's receive buffers for what comes from its left */
+    void *my_recv_left[2], *my_recv_right[2];   /* this rank's own receive buffers (device memory of its exported block) */
+    void *my_flag_left,  *my_flag_right;        /* this rank's own arrival flags */
+} sph_peer_links;
+int  sph_slab_set_peer_links(sph_ctx *ctx, const sph_peer_links *links);      /* between steps; NULL: none */
+int  sph_slab_step(sph_ctx *ctx, float gx, float gy);
 /* bytes of one halo buffer of a slab created with these parameters and this halo_capacity (0 = default): what a host
  * needs to know before it creates the context (shared-memory transports size their mailboxes with it) */
 size_t sph_slab_halo_bytes(const sph_params *prm, int halo_capacity);

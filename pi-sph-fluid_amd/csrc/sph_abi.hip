@@ -31,6 +31,9 @@ struct sph_ctx {
     bool slab = false;
     int slab_phase = 0;         // 0 idle, 1 after sph_slab_step_begin, 2 after sph_slab_step_pack
     bool slab_overlapped = false; // sph_slab_step_overlap ran in this step: step_end's density does the rest only
+    bool has_links = false;      // sph_slab_set_peer_links: the lean step (sph_slab_step) talks to the other ranks itself
+    sph_peer_links links{};
+    uint32_t lean_step = 0;      // steps taken by sph_slab_step / counted by the device (FLAG_STEP): the tags of its messages
     bool own_halo = false;      // halo buffers allocated by the library (else adopted from the host framework)
     size_t halo_bytes = 0;
     uint32_t *d_ids = nullptr;  // slab read-back staging
@@ -517,7 +520,10 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     uint32_t *&bkey = ctx->d_bkey;
     ALLOC(bpos_in, nb); ALLOC(bvel_in, nb); ALLOC(bkey, nb); ALLOC(ctx->d_bpsi0, nb); ALLOC(ctx->d_bcell_ids, nb);
     a.send[0] = a.send[1] = a.recv[0] = a.recv[1] = nullptr;
+    a.head_arrive = nullptr;
     if (slab) {
+        ALLOC(a.head_arrive, (size_t)2048 * 32);      // (k_slab_head: GATED_GRID_MAX check blocks x HEAD_STRIDE words)
+        HIPCHK(ctx, hipMemsetAsync(a.head_arrive, 0, sizeof(uint32_t) * (size_t)2048 * 32, ctx->stream));
         ctx->halo_bytes = sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * slab->halo_cap);
         for (int k = 0; k < 2; k++) { ALLOC(a.send[k], ctx->halo_bytes / 4); ALLOC(a.recv[k], ctx->halo_bytes / 4); }
         ctx->own_halo = true;
@@ -1097,6 +1103,9 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
         else launch_force(ctx->stream, ctx->c, ctx->a, ctx->cap, fused(ctx) ? FORCE_KICK_DRIFT : FORCE_KICK, ctx->variant);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    // (tiles of a speculative launch whose jobs raised the word have left early, or computed on a half-staged tile: in a step the gate
+    // rebuilds and repeats the pass — here the plain pass puts rho and p / rho^2 back, outside the timed interval)
+    if (kernel == SPH_K_DENSITY_SPEC) launch_density(ctx->stream, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false);
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
     float t = 0;
     HIPCHK(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
@@ -1189,6 +1198,83 @@ int sph_slab_step_end(sph_ctx *ctx) {
     return SPH_OK;
 }
 
+int sph_slab_set_peer_links(sph_ctx *ctx, const sph_peer_links *links) {
+    if (!ctx || !ctx->stream || !ctx->slab) return SPH_E_ARG;
+    if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_set_peer_links mid-step");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!links) { ctx->has_links = false; return SPH_OK; }
+    if (links->n_ranks < 1 || links->n_ranks > SPH_PEER_MAX_RANKS || links->me < 0 || links->me >= links->n_ranks)
+        return fail(ctx, SPH_E_ARG, "sph_slab_set_peer_links: rank out of range");
+    for (int q = 0; q < links->n_ranks; q++)
+        if (!links->slots_of_rank[q]) return fail(ctx, SPH_E_ARG, "sph_slab_set_peer_links: a rank's slot array is missing");
+    const bool l = ctx->c.has_left != 0, r = ctx->c.has_right != 0;
+    if ((l && !(links->left_recv[0] && links->left_recv[1] && links->left_flag && links->my_recv_left[0] && links->my_recv_left[1] && links->my_flag_left)) ||
+        (r && !(links->right_recv[0] && links->right_recv[1] && links->right_flag && links->my_recv_right[0] && links->my_recv_right[1] && links->my_flag_right)))
+        return fail(ctx, SPH_E_ARG, "sph_slab_set_peer_links: a neighbour's buffers or flags are missing");
+    ctx->links = *links;
+    ctx->has_links = true;
+    return SPH_OK;
+}
+
+int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
+    if (!ctx || !ctx->stream) return SPH_E_ARG;
+    if (!ctx->slab || ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_step: not a slab context, or mid-step");
+    if (ctx->rebuild_wgs <= 0)
+        return fail(ctx, SPH_E_STATE, "sph_slab_step needs the one-launch rebuild: sph_set_rebuild_launches(ctx, 1) (nothing else may compute on the device)");
+    if (!fused(ctx)) return fail(ctx, SPH_E_STATE, "sph_slab_step: list kernels only (variant 0)");
+    if ((ctx->c.has_left || ctx->c.has_right) && !ctx->has_links)
+        return fail(ctx, SPH_E_STATE, "sph_slab_step: this slab has neighbours: sph_slab_set_peer_links first (or the three-call step with a transport of the host's)");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    // kick 1/2 + drift of the owned range: the previous step's force pass made it (swap the sets), else the stand-alone kernel;
+    // either has left this step's update message in the send buffers
+    if (ctx->primed) {
+        std::swap(ctx->a.pos, ctx->a.pos2);
+        std::swap(ctx->a.vel, ctx->a.vel2);
+    } else {
+        refresh_velt(ctx);
+        launch_kick_drift(st, ctx->c, ctx->a, ctx->cap, true);
+    }
+    ctx->primed = true;
+    const uint32_t step = ++ctx->lean_step, par = step & 1u;
+    const sph_peer_links &L = ctx->links;
+    const bool peer = ctx->has_links && L.n_ranks > 1;
+    PeerHead ph = {};
+    PeerLinks pl = {};
+    ph.nranks = 1;
+    ph.step = pl.step = step;
+    if (peer) {
+        for (int q = 0; q < L.n_ranks; q++) ph.slots_of_rank[q] = static_cast<uint32_t *>(L.slots_of_rank[q]);
+        ph.my_slots = static_cast<const uint32_t *>(L.slots_of_rank[L.me]);
+        ph.me = L.me;
+        ph.nranks = L.n_ranks;
+        if (ctx->c.has_left) {
+            ph.remote_l = pl.remote_l = static_cast<uint32_t *>(L.left_recv[par]);
+            ph.flag_l = pl.flag_l = static_cast<uint32_t *>(L.left_flag);
+            pl.my_flag_l = static_cast<const uint32_t *>(L.my_flag_left);
+            ctx->a.recv[0] = static_cast<uint32_t *>(L.my_recv_left[par]);
+        }
+        if (ctx->c.has_right) {
+            ph.remote_r = pl.remote_r = static_cast<uint32_t *>(L.right_recv[par]);
+            ph.flag_r = pl.flag_r = static_cast<uint32_t *>(L.right_flag);
+            pl.my_flag_r = static_cast<const uint32_t *>(L.my_flag_right);
+            ctx->a.recv[1] = static_cast<uint32_t *>(L.my_recv_right[par]);
+        }
+    }
+    const float gravity[2] = {gx, gy};
+    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph);                                            // 1
+    launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 3 : 1, peer ? &pl : nullptr);   // 2
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, DENS_ALL, false);       // 3
+    launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);                            // 4
+    ctx->velt_stale = true;
+    ctx->acc_stale = true;
+    ctx->p_stale = true;
+    ctx->stepped = true;
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
 size_t sph_slab_halo_bytes(const sph_params *prm, int halo_capacity) {
     Consts cg;
     if (!prm || make_consts(*prm, cg) != SPH_OK) return 0;
@@ -1245,13 +1331,17 @@ int sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void *
     if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_set_buffers mid-step");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // (the send buffers hold the NEXT step's update message, written by the last force pass: it moves along)
+    uint32_t *const old_send[2] = {ctx->a.send[0], ctx->a.send[1]};
     ctx->a.send[0] = static_cast<uint32_t *>(send_left);
     ctx->a.send[1] = static_cast<uint32_t *>(send_right);
     ctx->a.recv[0] = static_cast<uint32_t *>(recv_left);
     ctx->a.recv[1] = static_cast<uint32_t *>(recv_right);
     ctx->own_halo = false;
     for (int k = 0; k < 2; k++) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, ctx->halo_bytes, ctx->stream));
+        if (old_send[k] && old_send[k] != ctx->a.send[k])
+            HIPCHK(ctx, hipMemcpyAsync(ctx->a.send[k], old_send[k], ctx->halo_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        else if (!old_send[k]) HIPCHK(ctx, hipMemsetAsync(ctx->a.send[k], 0, ctx->halo_bytes, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->a.recv[k], 0, ctx->halo_bytes, ctx->stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -125,8 +125,9 @@ struct Arrays {
     float *uref;        // where the density pass leaves the reference displacement (dyn + DYN_UREF_X; nullptr: slab contexts)
     float *dyn;         // DYN_COUNT floats: the list cut-off and the rebuild thresholds that follow from the current skin
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
-    // slab halo buffers: uint32 header[4] = {count,..} + halo_cap records of 5 words (x, y, u, v, id)
+    // slab halo buffers: uint32 header[4] (HALO_*) + halo_cap records of 5 words (x, y, u, v, id)
     uint32_t *send[2], *recv[2];   // [0] = left neighbour, [1] = right neighbour
+    uint32_t *head_arrive;         // slab contexts: one arrival word per check block of k_slab_head, HEAD_STRIDE words apart
 };
 
 enum {
@@ -158,7 +159,8 @@ enum {
                             //   position (the cap), 3 rest mode: somebody beyond skin/2
     FLAG_CHECK_DONE = 29,   // check jobs of the running density launch that have finished (spec_check_job; k_rebuild clears it)
     FLAG_SAVED_WORD = 30,   // sph_time_kernel(SPH_K_DENSITY_SPEC): the rebuild word as it was before the timed launches
-    FLAG_COUNT = 31
+    FLAG_HEAD_DONE = 31,    // push blocks of k_slab_head that have finished (grows: the last one of a launch raises the flags)
+    FLAG_COUNT = 32
 };
 // Arrays::dyn
 enum {
@@ -200,8 +202,12 @@ constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle lis
 #define SPH_VQ_CAP 4096
 #endif
 constexpr int VQ_CAP = SPH_VQ_CAP;    // pairs of groups the verification queue holds (more: rebuild)
-constexpr int HALO_HDR = 4;     // header words of a halo buffer
+constexpr int HALO_HDR = 4;     // header words of a halo buffer (below)
 constexpr int HALO_REC = 5;     // words per halo record
+// the header: [0] particles in the UPDATE message {x, y, u, v} and [1] the step it is for — written by the kernel that drifted the
+// particles (the force pass of the step before; k_kick_drift after creation / uploads); [2] full RECORDS {x, y, u, v, id} appended
+// and [3] the step they are for — zeroed by k_check at the start of every step, filled by the pack of a rebuild step.  One payload.
+enum { HALO_UPD_COUNT = 0, HALO_UPD_STEP = 1, HALO_REC_COUNT = 2, HALO_REC_STEP = 3 };
 
 constexpr int GBAR_MAX_WGS = 2048, GBAR_COPIES = 32, GBAR_STRIDE = 32;      // (words: 128 bytes apart)
 constexpr int GBAR_WORDS = GBAR_MAX_WGS + 8 + 8 * GBAR_COPIES + 8;      // arrivals, written back (per XCD), go (per XCD, in copies), leaders' XCDs
@@ -226,10 +232,29 @@ void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, i
                     bool spec = false);
 // slab mode, what follows the halo exchange, as one launch: ghost update, or (rebuild step) ingest -> scan -> scatter ->
 // canonical order of the interface cells -> tile records + lists
+// the lean slab step (sph_slab_step): what its two kernels that talk to the other ranks need of the links (by value)
+struct PeerHead {      // k_slab_head: k_check + the push of this step's update message + the MAX of the rebuild word
+    uint32_t *slots_of_rank[SPH_PEER_MAX_RANKS];      // every rank's slot array (as in sph_slab_peer_reduce)
+    const uint32_t *my_slots;
+    uint32_t *remote_l, *remote_r;                   // the neighbours' receive buffers of this step's parity (null: no neighbour)
+    uint32_t *flag_l, *flag_r;                       // ... and their arrival flags
+    int me, nranks;
+    uint32_t step;                                   // this step's number (flags[FLAG_STEP] once the kernel has counted it)
+};
+struct PeerLinks {     // k_rebuild_slab, lean: wait for the update | exchange the records of a rebuild step inside the launch
+    uint32_t *remote_l, *remote_r, *flag_l, *flag_r;
+    const uint32_t *my_flag_l, *my_flag_r;           // this rank's own arrival flags (what its neighbours raise)
+    uint32_t step;
+};
+void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph);
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag);
 void launch_peer_push(hipStream_t st, const Consts &c, const Arrays &a, void *remote_l, void *flag_l, void *remote_r, void *flag_r, uint32_t tag);
 void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const void *flag_r, uint32_t tag);
-void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool deterministic = false);
+// lean (sph_slab_step): bit 0 = the pack of a rebuild step (keys + histogram of the owned range, records into the send buffers) is
+// this launch's first phase instead of k_halo_out's; bit 1 = peer transport: the launch waits for the neighbours' update itself
+// and, on a rebuild step, pushes its records and waits for theirs between two of its grid barriers (links)
+void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool deterministic = false, int lean = 0,
+                         const PeerLinks *links = nullptr);
 // raise the rebuild request: the next step rebuilds the neighbour structure
 void launch_request_rebuild(hipStream_t st, const Arrays &a);
 // measurement (sph_time_kernel): what the gate does for the criterion jobs of a speculative density launch when nothing is

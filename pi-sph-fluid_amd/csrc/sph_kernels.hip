@@ -194,6 +194,29 @@ DEV void drift_verdict(const Consts &c, float ux, float uy, bool live, int group
     }
 }
 
+// The update message of the NEXT step, written by the kernel that has just drifted the particles (round 5; rounds 1-4 packed it
+// with a kernel of its own at the start of that step): particle i (sorted index) of this slab's two outermost owned columns on a
+// side with a neighbour -> entry i - (first particle of those columns) of that side's send buffer.  `first` = one thread of the
+// launch: the headers (count, the step the message is for).
+DEV void halo_update_write(const Consts &c, const uint32_t *__restrict__ cs, const int i, const bool mine, const float2 p, const float2 v,
+                           uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r, uint32_t *__restrict__ flags,
+                           const uint32_t for_step, const bool first) {
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        if (side == 0 ? !c.has_left : !c.has_right) continue;
+        const int col0 = side == 0 ? c.ghost : c.ghost + c.owned - 2;
+        const int beg = (int)cs[col0 * c.rows], n = (int)cs[(col0 + 2) * c.rows] - beg;
+        uint32_t *buf = side == 0 ? send_l : send_r;
+        if (first) {
+            buf[HALO_UPD_COUNT] = (uint32_t)min(n, c.halo_cap);
+            buf[HALO_UPD_STEP] = for_step;
+            if (n > c.halo_cap) atomicAdd(&flags[FLAG_CAPACITY], 1u);
+        }
+        const int t = i - beg;
+        if (mine && t >= 0 && t < n && t < c.halo_cap) reinterpret_cast<float4 *>(buf + HALO_HDR)[t] = make_float4(p.x, p.y, v.x, v.y);
+    }
+}
+
 // kick 1/2 + drift in place (:615-624), 48 B/particle: the stand-alone form (the first step after creation / upload —
 // afterwards the force pass does this for the next step, sph_list.inc).  One thread per tile lane (lrec: the lane's
 // particle), so that a wave is one box group here as in the force pass.
@@ -203,7 +226,8 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
                                                     float2 *__restrict__ vel, const uint32_t *__restrict__ cs,
                                                     const uint2 *__restrict__ lrec, float4 *__restrict__ wbox,
                                                     uint32_t *__restrict__ check, uint32_t *__restrict__ rebuild,
-                                                    const uint32_t *__restrict__ dn, const float *__restrict__ dyn) {
+                                                    const uint32_t *__restrict__ dn, const float *__restrict__ dyn,
+                                                    uint32_t *__restrict__ send_l, uint32_t *__restrict__ send_r) {
     // slab mode: only the OWNED range of the sorted arrays moves (cell_start of the last rebuild); the ghosts are
     // refreshed from their owners by the halo exchange of this step
     const int n = (int)dn[0];
@@ -214,9 +238,11 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
     const int i = t < n ? (int)lrec[t].x : n;
     const bool live = t < n && i >= own_lo && i < own_hi;
     float ux = 0.0f, uy = 0.0f;
+    float2 v = make_float2(0.0f, 0.0f), p = v;
     if (live) {
         const float2 a = acc[i], r = pos_ref[i];
-        float2 v = velt[i], p = pos[i];
+        v = velt[i];
+        p = pos[i];
         v.x = fmaf(c.half_dt, a.x, v.x);   // u += 0.5*DT*du_dt   :616
         v.y = fmaf(c.half_dt, a.y, v.y);
         p.x = fmaf(c.dt, v.x, p.x);        // x += DT*u           :622
@@ -226,14 +252,16 @@ __global__ __launch_bounds__(BLK) void k_kick_drift(Consts c, float2 *__restrict
         ux = p.x - r.x;
         uy = p.y - r.y;
     }
+    // slab mode: this step's update message for the neighbours (k_check, which counts the step, runs after this kernel)
+    if (SLAB) halo_update_write(c, cs, i, live, p, v, send_l, send_r, check - (int)FLAG_CHECK, check[(int)FLAG_STEP - (int)FLAG_CHECK] + 1u, t == 0);
     drift_verdict(c, ux, uy, live, t / BOXG, wbox, check, rebuild, dyn);
 }
 
 void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap, bool slab) {
     if (cap <= 0) return;
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
-    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn, a.dyn);
-    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn, a.dyn);
+    if (slab) hipLaunchKernelGGL(k_kick_drift<true>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn, a.dyn, a.send[0], a.send[1]);
+    else hipLaunchKernelGGL(k_kick_drift<false>, g, b, 0, st, c, a.pos, a.pos_ref, a.acc, a.velt, a.vel, a.cell_start, a.lrec, a.wbox, a.check, a.rebuild, a.dn, a.dyn, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -243,8 +271,12 @@ void launch_kick_drift(hipStream_t st, const Consts &c, const Arrays &a, int cap
 // staging entries 0..n_own-1, and every particle now inside a neighbour's reach (this slab's two outermost owned
 // columns, plus the column it may have migrated into since the last rebuild) is appended to that neighbour's halo
 // buffer as a full record: ONE exchange carries both the ghosts and the ownership migration.
+// Halo buffer header (4 words): [0] particles in the UPDATE message, [1] the step it is for (k_check's count of steps) — written
+// by the kernel that drifts the particles (the force pass of the step before; k_kick_drift after creation / uploads);
+// [2] full RECORDS appended so far, [3] the step they are for — zeroed by k_check at the start of every step, filled by the pack
+// of a rebuild step.  The payload behind the header is shared: update entries {x, y, u, v} or records {x, y, u, v, id}.
 DEV void halo_append(uint32_t *__restrict__ buf, int cap, float2 p, float2 v, uint32_t id, uint32_t *__restrict__ flags) {
-    const uint32_t k = atomicAdd(&buf[0], 1u);
+    const uint32_t k = atomicAdd(&buf[HALO_REC_COUNT], 1u);
     if (k < (uint32_t)cap) {
         uint32_t *r = buf + HALO_HDR + (size_t)k * HALO_REC;
         r[0] = __float_as_uint(p.x); r[1] = __float_as_uint(p.y);
@@ -304,7 +336,12 @@ DEV void key_hist_body(const Consts &c, const float2 *__restrict__ pos, const ui
     if (SLAB) {
         src0 = (int)cs[c.ghost * c.rows];
         n = (int)cs[(c.ghost + c.owned) * c.rows] - src0;
-        if (t == 0) dn[1] = (uint32_t)n;
+        if (t == 0) {
+            dn[1] = (uint32_t)n;
+            const uint32_t step = flags[FLAG_STEP];      // (counted by k_check at the start of this step)
+            if (send_l) send_l[HALO_REC_STEP] = step;
+            if (send_r) send_r[HALO_REC_STEP] = step;
+        }
     } else {
         n = (int)dn[0];
     }
@@ -401,21 +438,22 @@ constexpr int VERIFY_MAX = SPH_VERIFY_MAX;
 DEV bool check_group(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
                      const int w, const int k, const int own_lo, const int own_hi, const int own_safe, const float *__restrict__ dyn,
                      const bool verify, uint32_t (&fail_h)[VERIFY_MAX], int &nfail);
-__global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
-                                               const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
-                                               uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
-                                               const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
-                                               uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy,
-                                               const float *__restrict__ dyn) {
+// what k_check does, for workgroup `block` of `nblocks` (returns true when it had boxes to compare: the check word was set)
+DEV bool check_body(const Consts &c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
+                    const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
+                    uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
+                    const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
+                    uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy,
+                    const float *__restrict__ dyn, const int block, const int nblocks) {
     // the first kernel of every step: it counts them (the skin controller measures how many steps a set of lists lasted)
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_STEP], 1u);
+    if (block == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_STEP], 1u);
     // (slab mode: the gravity of this step rides along instead of taking a launch of its own)
-    if (grav && blockIdx.x == 0 && threadIdx.x == 0) *grav = make_float2(gx, gy);
-    // slab mode: this is the first kernel of a step; it also clears the headers of the send buffers (count, kind) for
-    // the pack that follows the reduction of the rebuild word
-    if (send_l && blockIdx.x == 0 && threadIdx.x < 2 * HALO_HDR) (threadIdx.x < HALO_HDR ? send_l : send_r)[threadIdx.x & (HALO_HDR - 1)] = 0u;
-    if (*check == 0u) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
+    if (grav && block == 0 && threadIdx.x == 0) *grav = make_float2(gx, gy);
+    // slab mode: this is the first kernel of a step; it also clears the record half of the send buffers' headers (count, step) for
+    // the pack that follows the reduction of the rebuild word on a rebuild step
+    if (send_l && block == 0 && threadIdx.x < 4) ((threadIdx.x & 2u) ? send_r : send_l)[HALO_REC_COUNT + (threadIdx.x & 1u)] = 0u;
+    if (*check == 0u) return false;
+    if (block == 0 && threadIdx.x == 0) atomicAdd(&flags[FLAG_NCHECK], 1u);
     const int n = (int)dn[0];
     // The ranks (tile order, see tile_rank) this rank integrates; single GPU: all of them.  A slab's owned columns begin
     // at a pair boundary (two ghost columns); they end at one when their number is even.  Otherwise the last owned column
@@ -429,7 +467,7 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
         own_safe = (int)cs[(c.ghost + c.owned - (c.owned & 1)) * c.rows];
     }
     // (a small grid striding over the groups: see k_key_hist)
-    for (int t = blockIdx.x * BLK + threadIdx.x; t < nw * CHECK_LANES; t += gridDim.x * BLK) {
+    for (int t = block * BLK + threadIdx.x; t < nw * CHECK_LANES; t += nblocks * BLK) {
         uint32_t fail_h[VERIFY_MAX] = {};
         int nfail = 0;
         if (check_group(c, wbox, wnbr, t / CHECK_LANES, t % CHECK_LANES, own_lo, own_hi, own_safe, dyn, false, fail_h, nfail)) {
@@ -437,6 +475,15 @@ __global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restric
             atomicAdd(&flags[FLAG_WHY_REBUILD + 0], 1u);
         }
     }
+    return true;
+}
+__global__ __launch_bounds__(BLK) void k_check(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
+                                               const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
+                                               uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
+                                               const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
+                                               uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy,
+                                               const float *__restrict__ dyn) {
+    (void)check_body(c, wbox, wnbr, cs, check, rebuild, flags, dn, send_l, send_r, nw, grav, gx, gy, dyn, (int)blockIdx.x, (int)gridDim.x);
 }
 // The boxes of group w against those of the groups in its range k.  Returns true: rebuild (two boxes have moved more than the skin
 // relative to each other and there is no verification, or more of them than a lane remembers); false: fine, or up to VERIFY_MAX
@@ -507,23 +554,6 @@ void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, 
 // particle id, k_canon), so the owner's two outermost owned columns and the neighbour's two ghost columns are the
 // SAME sequence of particles: the update is a plain copy of a contiguous range, 16 bytes per particle.
 // Buffer header: {count, kind, 0, 0}, kind 0 = full records (rebuild step), 1 = update.
-DEV void pack_update_body(const Consts &c, int side, int t, const float2 *__restrict__ pos, const float2 *__restrict__ vel,
-                          const uint32_t *__restrict__ cs, uint32_t *__restrict__ flags, uint32_t *__restrict__ send_l,
-                          uint32_t *__restrict__ send_r) {
-    if (side == 0 ? !c.has_left : !c.has_right) return;
-    const int col0 = side == 0 ? c.ghost : c.ghost + c.owned - 2;
-    const int beg = (int)cs[col0 * c.rows], n = (int)cs[(col0 + 2) * c.rows] - beg;
-    uint32_t *buf = side == 0 ? send_l : send_r;
-    if (t == 0) {
-        buf[0] = (uint32_t)min(n, c.halo_cap);
-        buf[1] = 1u;
-        if (n > c.halo_cap) atomicAdd(&flags[FLAG_CAPACITY], 1u);
-    }
-    if (t >= n || t >= c.halo_cap) return;
-    const float2 p = pos[beg + t], v = vel[beg + t];
-    reinterpret_cast<float4 *>(buf + HALO_HDR)[t] = make_float4(p.x, p.y, v.x, v.y);
-}
-
 DEV void unpack_update_body(const Consts &c, int side, int t, float2 *__restrict__ pos, float2 *__restrict__ vel,
                             const uint32_t *__restrict__ cs, uint32_t *__restrict__ flags, const uint32_t *__restrict__ recv_l,
                             const uint32_t *__restrict__ recv_r) {
@@ -531,17 +561,17 @@ DEV void unpack_update_body(const Consts &c, int side, int t, float2 *__restrict
     const int col0 = side == 0 ? 0 : c.ghost + c.owned;
     const int beg = (int)cs[col0 * c.rows], n = (int)cs[(col0 + c.ghost) * c.rows] - beg;
     const uint32_t *buf = side == 0 ? recv_l : recv_r;
-    // the neighbour must have sent an update of exactly my ghost range (same rebuild step, same canonical order)
-    if (t == 0 && (buf[0] != (uint32_t)n || buf[1] != 1u)) atomicAdd(&flags[FLAG_MISMATCH], 1u);
-    if (t >= n || t >= (int)buf[0]) return;
+    // the neighbour must have sent an update of exactly my ghost range (same rebuild step, same canonical order), for THIS step
+    if (t == 0 && (buf[HALO_UPD_COUNT] != (uint32_t)n || buf[HALO_UPD_STEP] != flags[FLAG_STEP])) atomicAdd(&flags[FLAG_MISMATCH], 1u);
+    if (t >= n || t >= (int)buf[HALO_UPD_COUNT]) return;
     const float4 q = reinterpret_cast<const float4 *>(buf + HALO_HDR)[t];
     pos[beg + t] = make_float2(q.x, q.y);
     vel[beg + t] = make_float2(q.z, q.w);
 }
 
-// What a slab sends in this step, one launch: on a rebuild step (the reduced word is set) keys + histogram of the
-// owned range with the full-record halo pack; otherwise the update pack.  Grid: max(particle blocks, 2 x halo blocks);
-// the send headers were zeroed by k_check at the start of the step.
+// What a slab sends on a REBUILD step (the reduced word is set): keys + histogram of the owned range with the full-record
+// halo pack; the record half of the send headers was zeroed by k_check at the start of the step.  On any other step
+// there is nothing to do: the update message was written by the kernel that drifted the particles (halo_update_write).
 __global__ __launch_bounds__(BLK) void k_halo_out(Consts c, const float2 *__restrict__ pos, const uint32_t *__restrict__ id,
                                                   const float2 *__restrict__ vel, const uint32_t *__restrict__ cs,
                                                   float2 *__restrict__ velk, float4 *__restrict__ pk,
@@ -556,12 +586,9 @@ __global__ __launch_bounds__(BLK) void k_halo_out(Consts c, const float2 *__rest
     if (word != 0u) {
         for (int vb = (int)blockIdx.x; vb < part_blocks; vb += (int)gridDim.x)
             key_hist_body<true>(c, pos, id, vel, cs, velk, pk, slot, count, dirty, flags, dn, send_l, send_r, vb, block_sums, dyn, word);
-    } else {
-        for (int vb = (int)blockIdx.x; vb < 2 * halo_blocks; vb += (int)gridDim.x) {
-            const int side = vb / halo_blocks;
-            pack_update_body(c, side, (vb - side * halo_blocks) * BLK + (int)threadIdx.x, pos, vel, cs, flags, send_l, send_r);
-        }
     }
+    // (any other step: the update message is in the send buffers already — halo_update_write, by the kernel that drifted)
+    (void)halo_blocks;
 }
 
 void launch_halo_out(hipStream_t st, const Consts &c, const Arrays &a, int cap) {
@@ -617,16 +644,18 @@ DEV void ingest_body(const Consts &c, const uint32_t *__restrict__ recv_l, const
                      uint32_t *__restrict__ count, uint32_t *__restrict__ dirty, uint32_t *__restrict__ flags,
                      uint32_t *__restrict__ dn, int stage_cap, uint32_t *__restrict__ block_sums, const int vblock) {
     const int n_own = (int)dn[1];
-    const int nl = c.has_left ? min((int)recv_l[0], c.halo_cap) : 0;
-    const int nr = c.has_right ? min((int)recv_r[0], c.halo_cap) : 0;
+    const int nl = c.has_left ? min((int)recv_l[HALO_REC_COUNT], c.halo_cap) : 0;
+    const int nr = c.has_right ? min((int)recv_r[HALO_REC_COUNT], c.halo_cap) : 0;
     const int t = vblock * BLK + threadIdx.x;
     if (t == 0) {
         int total = n_own + nl + nr;
         if (total > stage_cap) { atomicAdd(&flags[FLAG_CAPACITY], 1u); total = stage_cap; }
-        if ((c.has_left && (int)recv_l[0] > c.halo_cap) || (c.has_right && (int)recv_r[0] > c.halo_cap))
+        if ((c.has_left && (int)recv_l[HALO_REC_COUNT] > c.halo_cap) || (c.has_right && (int)recv_r[HALO_REC_COUNT] > c.halo_cap))
             atomicAdd(&flags[FLAG_CAPACITY], 1u);
         dn[0] = (uint32_t)total;
-        if ((c.has_left && recv_l[1] != 0u) || (c.has_right && recv_r[1] != 0u)) atomicAdd(&flags[FLAG_MISMATCH], 1u);
+        // (records of THIS step: a neighbour that did not rebuild in it has left the record half of its header zeroed)
+        const uint32_t step = flags[FLAG_STEP];
+        if ((c.has_left && recv_l[HALO_REC_STEP] != step) || (c.has_right && recv_r[HALO_REC_STEP] != step)) atomicAdd(&flags[FLAG_MISMATCH], 1u);
     }
     const bool mine = t < nl + nr && n_own + t < stage_cap;
     {   // the scan's per-tile totals: the records of a wave fall into one or two scan tiles -> one atomic per tile and wave
@@ -1121,8 +1150,9 @@ __global__ __launch_bounds__(BLK) void k_peer_push(const uint32_t *__restrict__ 
         const uint32_t *src = side == 0 ? send_l : send_r;
         uint32_t *dst = side == 0 ? remote_l : remote_r;
         if (!dst) continue;
-        const uint32_t count = min(src[0], (uint32_t)halo_cap), kind = src[1];
-        const uint32_t words = (uint32_t)HALO_HDR + count * (kind == 0u ? (uint32_t)HALO_REC : 4u), quads = (words + 3u) / 4u;
+        const bool records = src[HALO_REC_STEP] != 0u;      // (a rebuild step's pack has stamped it; zeroed by k_check otherwise)
+        const uint32_t count = min(src[records ? HALO_REC_COUNT : HALO_UPD_COUNT], (uint32_t)halo_cap);
+        const uint32_t words = (uint32_t)HALO_HDR + count * (records ? (uint32_t)HALO_REC : 4u), quads = (words + 3u) / 4u;
         const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
         uint4 *d4 = reinterpret_cast<uint4 *>(dst);
         for (uint32_t k = blockIdx.x * BLK + threadIdx.x; k < quads; k += gridDim.x * BLK) d4[k] = s4[k];
@@ -1144,6 +1174,98 @@ __global__ __launch_bounds__(64) void k_peer_wait(const uint32_t *__restrict__ f
     if (threadIdx.x == 0 && flag_l) (void)peer_wait(flag_l, tag, 0u, flags, v);
     if (threadIdx.x == 1 && flag_r) (void)peer_wait(flag_r, tag, 0u, flags, v);
 }
+// ---- the lean slab step (round 5): the head of a step as ONE launch ----
+// k_check (count the step, this step's gravity, the record half of the send headers, the boxes when somebody is beyond skin/2)
+// and — peer transport — what used to be two more launches: the push of this step's UPDATE message, which the last force pass
+// left in the send buffers, into the neighbours' receive buffers of this step's parity (then their arrival flags: tag 2 x step),
+// and the MAX of the rebuild word over the ranks.  Block order: [check blocks][push blocks][one exchange block]; the exchange
+// block is dispatched last and waits (bounded) for the check blocks' arrival words when there were boxes to compare.
+// The receive buffers are double-buffered by step parity: a neighbour's unpack of step t reads parity t & 1 while this rank,
+// a launch ahead, may already push step t + 1; parity t & 1 is written again in step t + 2, whose head follows this rank's
+// wait for that neighbour's step-t+1 message, which that neighbour pushed after its unpack of step t.
+constexpr int HEAD_PUSH_WGS = 16, HEAD_STRIDE = 32;      // (arrival words 128 bytes apart)
+__global__ __launch_bounds__(BLK) void k_slab_head(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
+                                                   const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
+                                                   uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
+                                                   const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
+                                                   uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy,
+                                                   const float *__restrict__ dyn, PeerHead ph, uint32_t *__restrict__ arrive,
+                                                   int ncheck, int npush) {
+    const int b = (int)blockIdx.x;
+    if (b < ncheck) {
+        const bool worked = check_body(c, wbox, wnbr, cs, check, rebuild, flags, dn, send_l, send_r, nw, grav, gx, gy, dyn, b, ncheck);
+        if (worked && ph.nranks > 1) {      // this block's verdict is in: tell the exchange block
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(arrive + (size_t)b * HEAD_STRIDE, ph.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    if (b < ncheck + npush) {      // this step's update message -> the neighbours (header rewritten: the record half is not this kernel's to copy)
+        const int pb = b - ncheck;
+        for (int side = 0; side < 2; side++) {
+            const uint32_t *src = side == 0 ? send_l : send_r;
+            uint32_t *dst = side == 0 ? ph.remote_l : ph.remote_r;
+            if (!dst) continue;
+            const uint32_t count = min(src[HALO_UPD_COUNT], (uint32_t)c.halo_cap);
+            if (pb == 0 && threadIdx.x == 0) reinterpret_cast<uint4 *>(dst)[0] = make_uint4(count, src[HALO_UPD_STEP], 0u, 0u);
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + HALO_HDR);
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst + HALO_HDR);
+            for (uint32_t k = (uint32_t)pb * BLK + threadIdx.x; k < count; k += (uint32_t)npush * BLK) d4[k] = s4[k];
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t arrived = atomicAdd(&flags[FLAG_HEAD_DONE], 1u);      // (grows by npush per launch: never reset)
+            if ((arrived + 1u) % (uint32_t)npush == 0u) {
+                __threadfence_system();
+                if (ph.flag_l) __hip_atomic_store(ph.flag_l, 2u * ph.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (ph.flag_r) __hip_atomic_store(ph.flag_r, 2u * ph.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    // the exchange block: the MAX of the rebuild word over the ranks (k_peer_reduce), once every check block has spoken
+    __shared__ uint32_t s_ok;
+    if (threadIdx.x == 0) s_ok = 1u;
+    __syncthreads();
+    if (*check != 0u) {
+        for (int w = (int)threadIdx.x; w < ncheck; w += BLK) {
+            uint32_t spins = 0u;
+            while (__hip_atomic_load(arrive + (size_t)w * HEAD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ph.step) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 22)) { s_ok = 0u; atomicOr(&flags[FLAG_BAR_TIMEOUT], 1u); break; }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (threadIdx.x >= 64u) return;
+    const int q = (int)threadIdx.x;
+    const uint32_t par = (ph.step & 1u) * (uint32_t)SPH_PEER_MAX_RANKS;
+    const uint32_t w = s_ok ? __hip_atomic_load(rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)REBUILD_CRITERION;
+    uint32_t got = w;
+    if (q < ph.nranks && q != ph.me) {
+        __hip_atomic_store(ph.slots_of_rank[q] + par + (uint32_t)ph.me, (ph.step << 2) | (w & 3u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t v = 0u;
+        if (peer_wait(ph.my_slots + par + (uint32_t)q, ph.step, 2u, flags, v)) got = v & 3u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) got = max(got, (uint32_t)__shfl_xor((int)got, d, 64));
+    if (q == 0) *rebuild = got;
+}
+void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph) {
+    if (cap <= 0) return;
+    const int nw = (cap + BOXG - 1) / BOXG;
+    const int ncheck = gated_grid((nw * CHECK_LANES + BLK - 1) / BLK);
+    const int npush = (ph.remote_l || ph.remote_r) ? HEAD_PUSH_WGS : 0, nxchg = ph.nranks > 1 ? 1 : 0;
+    hipLaunchKernelGGL(k_slab_head, dim3(ncheck + npush + nxchg), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check, a.rebuild,
+                       a.flags, a.dn, a.send[0], a.send[1], nw, a.grav, gravity[0], gravity[1], a.dyn, ph, a.head_arrive, ncheck, npush);
+}
+
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag) {
     PeerSlots ps;
     for (int q = 0; q < SPH_PEER_MAX_RANKS; q++) ps.of_rank[q] = q < nranks ? static_cast<uint32_t *>(slots_of_rank[q]) : nullptr;

@@ -15,8 +15,9 @@ columns (any other step).  This module is backend-agnostic host logic:
   TorchTransport       torch.distributed P2P (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" on CPU)
   SlabRunner           step loop: begin -> reduce the rebuild word -> pack -> exchange -> end
 
-Halo buffer format (include/sph.h): uint32 header[4] = {count, kind, 0, 0} then `count` records of
-5 words {x, y, u, v, id} (kind 0) or 4 words {x, y, u, v} (kind 1); fixed capacity, always sent
+Halo buffer format (include/sph.h): uint32 header[4] = {update count, update step, record count, record step}
+then one payload: records of 5 words {x, y, u, v, id} (a rebuild step) or update entries of 4 words
+{x, y, u, v} (any other step; written by the force pass of the step before); fixed capacity, always sent
 whole (messages are 0.1-1 MB: latency-bound on xGMI).
 """
 import ctypes as C

@@ -25,6 +25,7 @@ class OracleSlab:
         self.cap = halo_capacity
         words = sph.slab.halo_words(halo_capacity)
         self.bufs = [np.zeros(words, np.uint32) for _ in range(4)]     # send_l, send_r, recv_l, recv_r
+        self.step = 0                                                   # steps so far: full records carry the step they are for (include/sph.h)
         self.half_dt = 0.5 * float(np.float32(prm.dt))                  # 0.5*DT in double (:616)
         self.dt = np.float32(prm.dt)
         loc, ids = local if local is not None else sph.slab.local_subset(prm, fluid, c0, c1)
@@ -50,7 +51,7 @@ class OracleSlab:
         n = int(sel.sum())
         assert n <= self.cap, "halo capacity"
         buf[:] = 0
-        buf[0] = n
+        buf[2], buf[3] = n, self.step      # header {update count, its step, record count, their step}: this backend sends records every step
         rec = np.zeros((n, 5), np.uint32)
         for k, f in enumerate(("x", "y", "u", "v")):
             rec[:, k] = self.own[f][sel].view(np.uint32)
@@ -65,6 +66,7 @@ class OracleSlab:
 
     def step_begin(self, gx, gy):
         self.g = (gx, gy)
+        self.step += 1
         if getattr(self, "_flag", None) is not None:
             self._flag[0] = 1
         o = self.own
@@ -85,7 +87,8 @@ class OracleSlab:
         self._pack(self.bufs[1], (gc >= self.c1 - 2) if self.has_right else np.zeros(len(o), bool))
 
     def _unpack(self, buf):
-        n = int(buf[0])
+        n = int(buf[2])
+        assert int(buf[3]) == self.step, "records of another step: ranks out of step"
         rec = buf[4:4 + 5 * n].reshape(n, 5)
         q = np.zeros(n, self.orc.PARTICLE)
         for k, f in enumerate(("x", "y", "u", "v")):

@@ -7,10 +7,15 @@ inside the support and listed pairs beyond it contribute exactly 0.  These tests
   * trajectories do not depend on the skin beyond summation order, and match the oracle at the G5 tolerances,
   * skin = 0 rebuilds every step, skin > 0 rebuilds less often than every step.
 """
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import GX, GY, boundary_particles, load_golden, oracle_block_300, particles
+from conftest import GX, GY, ROOT, boundary_particles, load_golden, oracle_block_300, particles
 
 pytestmark = pytest.mark.gpu
 
@@ -438,3 +443,22 @@ def test_deterministic_runs_are_bit_identical(sph, orc):
         assert np.array_equal(acc[0], runs[first][1][0]) and np.array_equal(acc[1], runs[first][1][1])
         assert np.array_equal(a0[0], runs[first][2][0]) and reb == runs[first][3] and ver == runs[first][4]
     assert runs[2][3] > 3 and runs[2][4] == 0 and runs[0][4] > 0      # per phase: rebuilds, no verification; one launch: verification
+
+
+def test_speculative_pass_survives_waves_that_leave_early(sph):
+    """The speculative density pass returns at once when it finds the rebuild word raised — and the word can be raised by a job of
+    the same launch, so the waves of ONE workgroup may read it differently: some leave, the others go on with a tile that is only
+    partly staged (their results are thrown away: the gate rebuilds and repeats the pass).  Round 5 found what they must not do:
+    on a tile with more than two runs of rows the range table is loaded by the whole workgroup, and a staged index made of
+    whatever the LDS held was a memory access fault — rare with the plain load of the word (an XCD's L2 mostly keeps returning
+    the 0 it cached), every second run with the load made coherent.  The test build `make stress` (libsph_hip_co.so) IS that
+    coherent load: the developed dam break — splashes, tiles of many runs, verify jobs that raise the word — twice through it."""
+    lib = os.path.join(ROOT, "pi-sph-fluid_amd", "csrc", "libsph_hip_co.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "pi-sph-fluid_amd"), "stress"])
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-also", "--lib", lib, "--steps", "600", "--warmup", "3800"],
+                           capture_output=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0 and b"Memory access fault" not in r.stderr, r.stderr[-1500:]
+        out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+        assert out["neighbour_rebuilds_per_step"] > 0.01 and out["rebuild_requests"][1] > 0      # the verify jobs did raise the word
