@@ -687,6 +687,61 @@ def peer_leg(host, scene, world, steps, warmup, tilt, windows=1):
     return {"status": "ok", "raw": d}
 
 
+def slab_overhead(sph, out):
+    """What the SLAB path costs before any neighbour exists, at the two slab sizes of the multi-GPU runs — 2 000 000 particles
+    (the weak family's slab = cfg2) and 4 000 000 (one eighth of cfg4 as a tank of its own, under the tilt trace) — one rank of
+    the C host on this GPU against sph_step on the same particles, same windows: the lean step (sph_slab_step: head | update or
+    rebuild | density | force, four kernels: what a rank runs over the peer transport), the three-call step (six kernels), and
+    the three-call step with the per-step calls of either transport issued to the rank itself (--selfcomm: RCCL's all-reduce +
+    grouped send / receive; the peer transport's three kernels against its own block).  From the 4M figures: the most an
+    8-GPU strong-scaling run of cfg4 can gain — t(32M on one GPU) / t(its slab through the slab path), with perfect overlap of
+    everything between the ranks."""
+    host = os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid")
+
+    def c_host(scene, warmup, steps, windows, tilt, extra):
+        cmd = [host, "--ranks", "1", "--scene", scene, "--steps", str(steps), "--warmup", str(warmup), "--windows", str(windows)] + (["--tilt"] if tilt else []) + extra
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError("slab_sph_fluid %s: exit %d: %s" % (" ".join(extra), r.returncode, r.stderr.decode(errors="replace")[-300:]))
+        d = json.loads(lines[-1])
+        return {"timesteps_per_s": round(d["ticks_per_s"], 2), "window_timesteps_per_s": d.get("window_ticks_per_s"), "host": d["host"]}
+
+    variants = [("lean", "sph_slab_step: 4 kernels, no neighbour", []),
+                ("three_call", "the three-call step: 6 kernels, no neighbour", ["--lean", "0"]),
+                ("three_call_rccl_selfcomm", "three-call + the step's RCCL calls (all-reduce, grouped send / receive) to the rank itself",
+                 ["--lean", "0", "--selfcomm", "--transport", "rccl"]),
+                ("three_call_peer_selfcomm", "three-call + the peer transport's three kernels against the rank's own block",
+                 ["--lean", "0", "--selfcomm", "--transport", "peer"])]
+    res = {"workload": "slab_overhead: one slab through the C host vs sph_step on the same particles", "sizes": {}}
+    # 2M: cfg2 in the 8(d) protocol — sph_step's figure is the `sustained` entry of this line
+    one = out.get("sustained", {}).get("timesteps_per_s")
+    size = {"n_fluid": 2000000, "window": [200, 1000, 5], "sph_step_timesteps_per_s": one}
+    for key, what, extra in variants:
+        r = c_host("dam", 200, 1000, 5, False, extra)
+        size[key] = dict(r, what=what, vs_sph_step=round(r["timesteps_per_s"] / one, 4) if one else None)
+        log("slab_overhead 2M %s: %s" % (key, size[key]))
+    res["sizes"]["2M (the weak family's slab = cfg2)"] = size
+    # 4M: one of cfg4's eight slabs as a tank of its own, tilt trace, cfg4's at-rest window
+    key4, wu, st_, wn = STRONG_LEGS["at_rest"]
+    r1 = run_single(sph, "cfg4_slab", st_, wu, profile_steps=5, tilt=True, windows=wn)
+    size = {"n_fluid": r1["n_fluid"], "window": [wu, st_, wn], "sph_step_timesteps_per_s": round(r1["steps_per_s"], 2),
+            "sph_step_window_timesteps_per_s": r1["window_steps_per_s"]}
+    for key, what, extra in variants:
+        r = c_host("cfg4slab", wu, st_, wn, True, extra)
+        size[key] = dict(r, what=what, vs_sph_step=round(r["timesteps_per_s"] / r1["steps_per_s"], 4))
+        log("slab_overhead 4M %s: %s" % (key, size[key]))
+    t32 = next((e["timesteps_per_s"] for e in out.get("also", []) if e.get("cache_key") == key4), None)
+    if t32:
+        size["cfg4_one_gpu_timesteps_per_s"] = t32
+        size["strong_scaling_upper_bound_8_gpus"] = {k: round(size[k]["timesteps_per_s"] / t32, 2) for k, _w, _e in variants}
+        size["strong_scaling_upper_bound_8_gpus"]["sph_step_on_the_slab"] = round(r1["steps_per_s"] / t32, 2)
+    res["sizes"]["4M (one of cfg4's eight slabs, tilt trace, at rest)"] = size
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -829,6 +884,12 @@ def main():
         log("also:", json.dumps(r))
         out["also"].append(also_entry("cfg4 on one GPU, developed flow: steps 2000-2600 of the same run", r, "cfg4_developed",
                                       "cfg4_developed" if args.skin is None else None))
+    if not args.no_also and args.workload == "cfg2" and args.skin is None and not args.load_state and not args.lib:
+        try:
+            out["also"].append(slab_overhead(sph, out))
+        except Exception as e_:      # (reported, never raised)
+            log("slab_overhead failed: %r" % (e_,))
+            out["also"].append({"workload": "slab_overhead", "status": "failed: %r" % (e_,)})
     if out.get("also") and args.skin is None and not args.load_state and not args.lib:
         # the N > 1 runs of this host quote these (weak efficiency, strong speed-ups): by leg, each with its window; only what the
         # library's defaults measured (a fixed skin, a checkpoint or another build are A/B runs)

@@ -193,7 +193,10 @@ size_t sph_device_bytes(const sph_ctx *ctx);
  * in one process or in several, and the library cannot see the other processes.  A host that calls this with
  * one_launch = 1 on a slab context vouches that nothing else computes on that device while the slab steps: one rank per
  * GPU (the C multi-GPU host over RCCL does), or slabs of one device stepped strictly one after the other with a
- * synchronisation in between.  Results are the same either way. */
+ * synchronisation in between.  Results are the same either way.  one_launch > 1: the same with at most that many workgroups
+ * (a multiple of 8) — ranks that DO share a device may cap their grids so that all of them are resident together (the grid
+ * barriers need that; a barrier that cannot complete gives up after a few seconds: SPH_E_STATE): rehearsals of the multi-rank
+ * step on one GPU. */
 int  sph_set_rebuild_launches(sph_ctx *ctx, int one_launch);
 int  sph_get_rebuild_launches(const sph_ctx *ctx);      /* 1: one launch, 0: one kernel per phase (as of the last step) */
 

@@ -44,7 +44,7 @@ ABI_SYMBOLS = [      # include/sph.h: the drop-in boundary (+ slabs, metaballs)
     "sph_set_stream", "sph_device_bytes",
     "sph_render_metaballs",
     "sph_create_slab", "sph_slab_step_begin", "sph_slab_step_pack", "sph_slab_step_overlap", "sph_slab_step_overlap_on", "sph_slab_step_end",
-    "sph_slab_peer_reduce", "sph_slab_peer_push", "sph_slab_peer_wait",
+    "sph_slab_peer_reduce", "sph_slab_peer_push", "sph_slab_peer_wait", "sph_slab_set_peer_links", "sph_slab_step",
     "sph_slab_flag_buffer", "sph_slab_set_flag_buffer", "sph_slab_flag_get", "sph_slab_flag_set", "sph_slab_buffers", "sph_slab_set_buffers",
     "sph_slab_copy_out", "sph_slab_copy_in", "sph_slab_read", "sph_slab_counts", "sph_slab_halo_bytes",
 ]
@@ -288,6 +288,7 @@ BLOCK_SCENES = {
     "cfg2": ((0.0, 1200.0, 0.0, 60.0), 0.3, 0.3, 4000, 500),
     "cfg3": ((0.0, 2400.0, 0.0, 60.0), 0.3, 0.3, 16000, 500),
     "cfg4": ((0.0, 2400.6, 0.0, 150.0), 0.3, 0.3, 32000, 1000),
+    "cfg4_slab": ((0.0, 300.6, 0.0, 150.0), 0.3, 0.3, 4000, 1000),      # one eighth of cfg4 as a tank of its own: what one GPU of the 8-GPU run holds
 }
 
 
@@ -307,6 +308,8 @@ def scene(name):
         return scene_block((0.0, 2400.0, 0.0, 60.0), 0.3, 0.3, 16000, 500)
     if name == "cfg4":      # 32M tank (8 x-slabs)
         return scene_block((0.0, 2400.6, 0.0, 150.0), 0.3, 0.3, 32000, 1000)
+    if name == "cfg4_slab":      # 4M: the particles of one of cfg4's eight slabs (bench.py: the slab step's overhead at that size)
+        return scene_block((0.0, 300.6, 0.0, 150.0), 0.3, 0.3, 4000, 1000)
     raise ValueError("unknown scene %r" % name)
 
 

@@ -925,6 +925,11 @@ int sph_set_rebuild_launches(sph_ctx *ctx, int one_launch) {
     ctx->one_launch_asked = one_launch != 0;
     ctx->rebuild_wgs = one_launch ? rebuild_grid(ctx->device, ctx->cap) : 0;
     if (one_launch && ctx->rebuild_wgs <= 0) return fail(ctx, SPH_E_HIP, "occupancy query for the one-launch rebuild failed");
+    if (one_launch > 1) {      // a cap on the grid: several contexts whose hosts vouch that ALL their one-launch grids fit the device together
+        const int capg = one_launch - one_launch % 8;
+        if (capg < 8) return fail(ctx, SPH_E_ARG, "sph_set_rebuild_launches: a grid cap below 8 workgroups");
+        if (ctx->rebuild_wgs > capg) ctx->rebuild_wgs = capg;
+    }
     if (one_launch) {
         int rc = selftest_one_launch(ctx);
         if (rc) return rc;

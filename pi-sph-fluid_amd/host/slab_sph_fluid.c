@@ -26,10 +26,10 @@
  *         one GPU per rank this is the transport without a collective library on the step path.  Up to 8 ranks.
  * The three differ only in the functions under "transport" below; the step loop is one.
  *
- *   slab_sph_fluid --ranks N [--transport rccl|host|peer] [--scene dam|cfg3|cfg4] [--block NX NY BOXW BOXH] [--origin X0 Y0]
+ *   slab_sph_fluid --ranks N [--transport rccl|host|peer] [--scene dam|cfg3|cfg4|cfg4slab] [--block NX NY BOXW BOXH] [--origin X0 Y0]
  *                  [--velocity U V] [--steps K] [--warmup W] [--windows N] [--tilt] [--check] [--deterministic] [--skin F]
  *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE]
- *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K]
+ *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--one-launch-wgs N]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
  * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
  * what may sit under a profiler; the launcher must not: see profiles/README.md).  The ncclUniqueId travels through a file
@@ -48,6 +48,10 @@
  * --breakdown K: K more steps after the timed ones with HIP events at the phase boundaries, per rank (begin / reduction of the
  * word / pack / exchange / end, us per step), printed per rank in the JSON line with its device, its particle counts and the
  * ranks its communicator counts (ncclCommCount): one run tells an overloaded rank from a slow interconnect.
+ * --lean (default auto): the step as ONE call (sph_slab_step: four kernels — head, ghost update or rebuild, density, force — with the
+ * update message written by the force pass of the step before and everything between the ranks inside those kernels) where that is
+ * possible: the peer transport, or a slab without neighbours, and the device this rank's alone (or --one-launch-wgs N: ranks that
+ * share a device cap the grids of their one-launch kernels so that all of them stay resident — tests).  0: the three-call step.
  * --selfcomm (N = 1, rccl; a measurement): the all-reduce and the grouped send / receive of every step are issued anyway,
  * to this rank itself: what the RCCL calls of a step cost (enqueue + their kernels) before any neighbour is waited for.
  */
@@ -150,6 +154,8 @@ static int comm_reduce_word(comm *cm, sph_ctx *ctx, void *dev_word, hipStream_t 
     SPHCHK(ctx, sph_slab_flag_set(ctx, f > 0.0f ? 1u : 0u));
     return 0;
 }
+
+static int deterministic_blocks_lean(int deterministic) { (void)deterministic; return 0; }      /* (the lean step keeps the deterministic order: nothing to exclude) */
 
 typedef struct xchg {      /* what the exchange of a step needs besides the communicator */
     void *send_l, *send_r, *recv_l, *recv_r;
@@ -412,6 +418,8 @@ typedef struct rank_state {
     comm cm;
     int device, transport, deterministic, capacity, halo_capacity;
     int own_device;              /* no other rank of this run on this rank's device (peer: as many devices as ranks) */
+    int lean;                    /* the step is ONE call, sph_slab_step: four kernels, the exchange inside them (peer transport, or a slab alone) */
+    int one_launch_wgs;          /* > 0: the one-launch kernels of this rank use at most so many workgroups (ranks sharing a device: they must all be resident) */
     sph_particle *walls;
     long nw;
     hipStream_t st, xst;
@@ -430,10 +438,13 @@ typedef struct rank_state {
     int bd_on;                   /* record them in this step */
 } rank_state;
 
-/* layout of a peer block: [send_l][send_r][recv_l][recv_r][flag from left | flag from right (256 B apart)][slots] */
-static size_t peer_off_recv(const rank_state *rs, int side) { return (size_t)(2 + side) * rs->peer_halo; }
-static size_t peer_off_flag(const rank_state *rs, int side) { return 4 * rs->peer_halo + (size_t)side * 256; }
-static size_t peer_off_slots(const rank_state *rs) { return 4 * rs->peer_halo + 512; }
+/* layout of a peer block: [send_l][send_r][recv_l, parity 0][recv_r, 0][recv_l, 1][recv_r, 1][flag from left | flag from right (256 B apart)][slots]
+ * (the second pair of receive buffers: the lean step pushes the message of step t into parity t & 1 — see sph_slab_step in sph.h;
+ * the three-kernel peer step uses parity 0 only) */
+static size_t peer_off_recv2(const rank_state *rs, int side, int parity) { return (size_t)(2 + 2 * parity + side) * rs->peer_halo; }
+static size_t peer_off_recv(const rank_state *rs, int side) { return peer_off_recv2(rs, side, 0); }
+static size_t peer_off_flag(const rank_state *rs, int side) { return 6 * rs->peer_halo + (size_t)side * 256; }
+static size_t peer_off_slots(const rank_state *rs) { return 6 * rs->peer_halo + 512; }
 static size_t peer_block_bytes(const rank_state *rs) { return peer_off_slots(rs) + sizeof(uint32_t) * 2 * SPH_PEER_MAX_RANKS + 256; }
 
 /* allocate and export this rank's block, open the others' (collective; once per run: the block outlives re-balancing) */
@@ -506,10 +517,32 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
     SPHCHK(rs->ctx, sph_set_stream(rs->ctx, rs->st));
     /* one rank per GPU (rccl): nothing else computes on this device, so what follows the halo exchange may run as one
      * launch with grid barriers (include/sph.h, sph_set_rebuild_launches); ranks that may share a device must not */
-    if (rs->transport == TR_RCCL || (rs->transport == TR_PEER && rs->own_device)) SPHCHK(rs->ctx, sph_set_rebuild_launches(rs->ctx, 1));
+    if (rs->one_launch_wgs > 0) SPHCHK(rs->ctx, sph_set_rebuild_launches(rs->ctx, rs->one_launch_wgs));      /* (a capped grid: ranks that share a device) */
+    else if (rs->transport == TR_RCCL || rs->lean || (rs->transport == TR_PEER && rs->own_device)) SPHCHK(rs->ctx, sph_set_rebuild_launches(rs->ctx, 1));
     if (rs->transport == TR_PEER) {      /* the context sends from and receives into this rank's block */
         char *b = (char *)rs->peer_blk;
         SPHCHK(rs->ctx, sph_slab_set_buffers(rs->ctx, b, b + rs->peer_halo, b + peer_off_recv(rs, 0), b + peer_off_recv(rs, 1), rs->peer_halo));
+    }
+    if (rs->lean && rs->transport == TR_PEER && rs->cm.nranks > 1) {      /* the lean step talks to the other ranks' blocks itself */
+        const int me = rs->cm.rank, n = rs->cm.nranks;
+        sph_peer_links L;
+        memset(&L, 0, sizeof L);
+        L.me = me;
+        L.n_ranks = n;
+        for (int q = 0; q < n; q++) L.slots_of_rank[q] = (char *)rs->peer_of[q] + peer_off_slots(rs);
+        char *M = (char *)rs->peer_blk;
+        for (int par = 0; par < 2; par++) {
+            L.my_recv_left[par] = M + peer_off_recv2(rs, 0, par);
+            L.my_recv_right[par] = M + peer_off_recv2(rs, 1, par);
+            /* my left neighbour receives me on ITS right side, and the other way round */
+            if (desc.has_left) L.left_recv[par] = (char *)rs->peer_of[me - 1] + peer_off_recv2(rs, 1, par);
+            if (desc.has_right) L.right_recv[par] = (char *)rs->peer_of[me + 1] + peer_off_recv2(rs, 0, par);
+        }
+        L.my_flag_left = M + peer_off_flag(rs, 0);
+        L.my_flag_right = M + peer_off_flag(rs, 1);
+        if (desc.has_left) L.left_flag = (char *)rs->peer_of[me - 1] + peer_off_flag(rs, 1);
+        if (desc.has_right) L.right_flag = (char *)rs->peer_of[me + 1] + peer_off_flag(rs, 0);
+        SPHCHK(rs->ctx, sph_slab_set_peer_links(rs->ctx, &L));
     }
     SPHCHK(rs->ctx, sph_slab_flag_buffer(rs->ctx, &rs->flag));
     SPHCHK(rs->ctx, sph_slab_buffers(rs->ctx, &rs->x.send_l, &rs->x.send_r, &rs->x.recv_l, &rs->x.recv_r, &rs->x.halo_bytes));
@@ -533,6 +566,11 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
 #define BD(k) do { if (rs->bd_on) HIPCHK(hipEventRecord(rs->bev[k], rs->st)); } while (0)
 static int step_once(rank_state *rs, float gx, float gy) {
     BD(0);
+    if (rs->lean) {      /* one call, four kernels (head | ghost update or rebuild | density | force): sph.h, "the lean slab step" */
+        SPHCHK(rs->ctx, sph_slab_step(rs->ctx, gx, gy));
+        BD(1); BD(2); BD(3); BD(4); BD(5);      /* (the breakdown has nothing to tell apart: the whole step shows as `begin`) */
+        return 0;
+    }
     SPHCHK(rs->ctx, sph_slab_step_begin(rs->ctx, gx, gy));
     BD(1);
     if (rs->cm.kind == TR_PEER) {
@@ -670,6 +708,13 @@ static int rebalance(rank_state *rs, float gx, float gy, double min_gain, int *m
     HIPCHK(hipStreamSynchronize(rs->st));
     HIPCHK(hipStreamSynchronize(rs->xst));
     sph_destroy(rs->ctx);
+    if (rs->lean && rs->transport == TR_PEER) {
+        /* the lean step's tags are step numbers, and the new contexts count from 1 again: this rank's arrival flags and word slots
+         * start from 0 too (nobody writes into them before the barrier at the end of this function, which every rank reaches
+         * only after this) */
+        HIPCHK(hipMemset((char *)rs->peer_blk + peer_off_flag(rs, 0), 0, peer_block_bytes(rs) - peer_off_flag(rs, 0)));
+        HIPCHK(hipDeviceSynchronize());
+    }
     CHK(make_context(rs, cuts[cm->rank], cuts[cm->rank + 1], loc, lid, (long)n_in, gx, gy));
     HIPCHK(hipStreamSynchronize(rs->st));
     CHK(comm_barrier(cm));      /* (nobody steps before every rank has its new context: see main) */
@@ -683,6 +728,7 @@ static int rebalance(rank_state *rs, float gx, float gy, double min_gain, int *m
 int main(int argc, char **argv) {
     int nranks = 1, rank = -1, steps = 200, warmup = 50, windows = 1, tilt = 0, check = 0, deterministic = 0, transport = TR_RCCL;
     int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2, breakdown = 0, halo_capacity = -1;
+    int lean_opt = -1, one_launch_wgs = 0;      /* --lean auto (-1) | 0 | 1; --one-launch-wgs N: cap of the one-launch kernels' grid (ranks that share a device) */
     float skin = -1;
     const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL;
     scene_t sc = {0, 0, 0.3f, 0.3f, 0, 0, 0, 0, NULL};
@@ -711,6 +757,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--tilt")) tilt = 1;
         else if (!strcmp(argv[i], "--console")) console = 1;
         else if (!strcmp(argv[i], "--selfcomm")) selfcomm = 1;
+        else if (!strcmp(argv[i], "--lean") && i + 1 < argc) { i++; lean_opt = !strcmp(argv[i], "auto") ? -1 : atoi(argv[i]); }
+        else if (!strcmp(argv[i], "--one-launch-wgs") && i + 1 < argc) one_launch_wgs = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--exchange-stream") && i + 1 < argc) { i++; xside = !strcmp(argv[i], "side") ? 1 : !strcmp(argv[i], "main") ? 0 : 2; }
         else if (!strcmp(argv[i], "--deterministic")) deterministic = 1;
         else if (!strcmp(argv[i], "--skin") && i + 1 < argc) skin = (float)atof(argv[++i]);
@@ -730,6 +778,7 @@ int main(int argc, char **argv) {
         if (!strcmp(scene_name, "dam")) { sc.nx = 4000L * nranks; sc.ny = 500; sc.box_w = 1200.0f * (float)nranks; sc.box_h = 60.0f; sc.label = "dam break, 2 000 000 fluid particles per slab"; }
         else if (!strcmp(scene_name, "cfg3")) { sc.nx = 16000; sc.ny = 500; sc.box_w = 2400.0f; sc.box_h = 60.0f; sc.label = "cfg3: 8M dam break"; }
         else if (!strcmp(scene_name, "cfg4")) { sc.nx = 32000; sc.ny = 1000; sc.box_w = 2400.6f; sc.box_h = 150.0f; sc.label = "cfg4: 32M tank"; }
+        else if (!strcmp(scene_name, "cfg4slab")) { sc.nx = 4000; sc.ny = 1000; sc.box_w = 300.6f; sc.box_h = 150.0f; sc.label = "cfg4's slab: 4M tank"; }
         else { fprintf(stderr, "unknown scene %s\n", scene_name); return 2; }
     }
     sph_params prm;
@@ -818,6 +867,15 @@ int main(int argc, char **argv) {
     }
     rs.device = transport == TR_RCCL ? rank : rank % ndev;
     rs.own_device = nranks <= ndev;
+    rs.one_launch_wgs = one_launch_wgs;
+    /* The lean step needs the one-launch kernels (the device is this rank's alone, or the ranks that share it cap their grids so
+     * that all stay resident) and a transport that lives inside the step's kernels: peer-mapped memory — or no neighbour at all. */
+    {
+        const int can = (rs.own_device || one_launch_wgs > 0) && !selfcomm && !deterministic_blocks_lean(deterministic) &&
+                        (nranks == 1 || transport == TR_PEER);
+        rs.lean = lean_opt < 0 ? can : (lean_opt && can);
+        if (lean_opt > 0 && !can) { fprintf(stderr, "[rank %d] --lean 1 needs --transport peer (or one rank) and the device to itself (or --one-launch-wgs)\n", rank); return 2; }
+    }
     HIPCHK(hipSetDevice(rs.device));
     HIPCHK(hipStreamCreateWithFlags(&rs.st, hipStreamNonBlocking));      /* compute stream (adopted by the context) ... */
     HIPCHK(hipStreamCreateWithFlags(&rs.xst, hipStreamNonBlocking));     /* ... and exchange stream */
@@ -1015,12 +1073,13 @@ int main(int argc, char **argv) {
     }
     if (rank == 0) {
         const double tps = steps > 0 ? (double)steps / elapsed : 0.0;
-        printf("{\"host\": \"slab_sph_fluid (C, %s)\", \"workload\": \"%s%s\", \"n_gpus\": %d, \"n_fluid\": %ld, \"n_boundary\": %ld, "
+        printf("{\"host\": \"slab_sph_fluid (C, %s%s)\", \"workload\": \"%s%s\", \"n_gpus\": %d, \"n_fluid\": %ld, \"n_boundary\": %ld, "
                "\"steps\": %d, \"warmup\": %d, \"windows\": %d, \"ticks_per_s\": %.2f, \"mparticle_steps_per_s\": %.2f, \"ms_per_step\": %.5f, "
                "\"neighbour_rebuilds\": %lld, \"rebalanced\": %d, \"max_owned\": %lld, \"max_rho\": %.3f, \"max_speed\": %.3f, "
                "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s, "
                "\"halo_buffer_bytes\": %zu, \"breakdown_steps\": %d, \"per_rank\": [",
-               transport == TR_RCCL ? "RCCL" : transport == TR_PEER ? "peer-mapped memory" : "host-staged shared memory", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
+               transport == TR_RCCL ? "RCCL" : transport == TR_PEER ? "peer-mapped memory" : "host-staged shared memory",
+               rs.lean ? ", lean step: 4 kernels" : "", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
                steps, warmup, n_win, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
                n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false", rs.x.halo_bytes, bd_ok ? breakdown : 0);
         for (int r = 0; r < nranks; r++) {

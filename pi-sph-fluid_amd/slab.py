@@ -190,6 +190,12 @@ class GpuSlab:
     def step_end(self):
         self._chk(self.L.sph_slab_step_end(self.h))
 
+    def step_lean(self, gx, gy):
+        """the whole step as ONE call (sph_slab_step: four kernels); a slab without neighbours, or with peer links set by its host;
+        needs set_rebuild_launches(True)"""
+        self.L.sph_slab_step.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        self._chk(self.L.sph_slab_step(self.h, gx, gy))
+
     # the rebuild word
     def flag_get(self):
         v = C.c_uint32()

@@ -58,14 +58,18 @@ def test_c_host_fails_loudly_without_gpu(sph):
 
 
 @pytest.mark.gpu
-def test_c_host_one_rank_equals_sph_step(sph):
-    r = subprocess.run([HOST, "--ranks", "1", "--block", "600", "150", "90", "20", "--steps", "150", "--warmup", "50", "--check"],
+@pytest.mark.parametrize("lean", ["auto", "0"])
+def test_c_host_one_rank_equals_sph_step(sph, lean):
+    """one slab through the C host against sph_step (--check): as the lean step (round 5: one call, four kernels — what a rank
+    without neighbours and with the device to itself gets by default) and as the three-call step (--lean 0)"""
+    r = subprocess.run([HOST, "--ranks", "1", "--block", "600", "150", "90", "20", "--steps", "150", "--warmup", "50", "--check", "--lean", lean],
                        capture_output=True, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     out = r.stdout.decode().splitlines()
     rec = json.loads([ln for ln in out if ln.startswith("{")][0])      # (RCCL prints a version banner on stdout first)
     assert rec["n_gpus"] == 1 and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True
     assert rec["ticks_per_s"] > 0 and 0 < rec["neighbour_rebuilds"] < 200
+    assert ("lean step" in rec["host"]) == (lean == "auto")
     chk = [ln for ln in out if ln.startswith("check:")]
     assert len(chk) == 1 and chk[0].endswith("-> ok"), chk
 
@@ -178,6 +182,60 @@ def test_c_host_ranks_over_peer_mapped_memory_equal_sph_step_bitwise(sph, tmp_pa
     assert len(got) == len(ref)
     for k in ("x", "y", "u", "v", "rho", "p"):
         assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_c_host_lean_step_over_peer_mapped_memory_equals_sph_step_bitwise(sph, tmp_path, ranks):
+    """The LEAN step (sph_slab_step: head | ghost update or rebuild | density | force — four kernels, nothing of the exchange as a
+    launch of its own) with real neighbours, on one GPU: the ranks cap the grids of their one-launch kernels (--one-launch-wgs)
+    so that all of them stay resident.  Skin 0: every step rebuilds — the pack as the first phase of the rebuild launch, the
+    records pushed into the neighbours' mapped receive buffers and theirs awaited between two of its grid barriers, the rebuild
+    word exchanged by the head kernel.  Bit for bit sph_step's particles after 300 steps of a block flying through the
+    interfaces."""
+    state = tmp_path / "state.bin"
+    r, out, rec = _run_host(["--ranks", ranks, "--transport", "peer", "--lean", 1, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
+                             "--velocity", 5, 0, "--steps", 250, "--warmup", 50, "--deterministic", "--skin", 0, "--dump-state", state])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["n_gpus"] == ranks and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True and rec["neighbour_rebuilds"] >= 300
+    assert "peer-mapped" in rec["host"] and "lean step" in rec["host"]
+    got = np.fromfile(state, sph.PARTICLE)
+    prm, f, b = _flying_block(sph)
+    with sph.Context(prm, f, b, 0.0, -9.81) as ctx:
+        ctx.step(300, 0.0, -9.81)
+        ctx.sync()
+        ref = ctx.read_particles()
+    assert len(got) == len(ref)
+    for k in ("x", "y", "u", "v", "rho", "p"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.gpu
+def test_c_host_lean_step_updates_equal_the_three_call_step_bitwise(sph, tmp_path):
+    """... and with the default (adaptive) skin, where most steps carry UPDATES: the message the force pass of the step before left
+    in the send buffers, pushed by the head kernel into the parity buffer of the step, awaited by the ghost-update launch itself.
+    Three ranks, 400 steps, deterministic order: the same bits as the three-call step over the same transport (which packs
+    nothing either any more, but pushes and waits with kernels of its own) — and re-balancing on top (contexts re-created, the
+    peer blocks and their flags kept) ends cleanly with every particle owned once."""
+    states = []
+    for lean in (1, 0):
+        state = tmp_path / ("state%d.bin" % lean)
+        r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", lean, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
+                                 "--velocity", 5, 0, "--steps", 300, "--warmup", 100, "--deterministic", "--dump-state", state])
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200 and ("lean step" in rec["host"]) == bool(lean)
+        states.append((np.fromfile(state, sph.PARTICLE), rec["neighbour_rebuilds"]))
+    assert states[0][1] == states[1][1]                                  # the ranks rebuilt in the same steps
+    for k in ("x", "y", "u", "v", "rho", "p"):
+        assert np.array_equal(states[0][0][k], states[1][0][k]), k
+    # re-balancing under the lean step: the block of test_c_host_rebalancing_..., flying along x at 30 m/s out of the first slab and
+    # into the last — the contexts are re-created (their step counts, the tags of the lean step's messages, start from 1 again:
+    # the flags and word slots of the peer blocks with them)
+    r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--one-launch-wgs", 256, "--block", 160, 40, 60, 6,
+                             "--origin", 2.0, 1.5, "--velocity", 30, 0, "--capacity", 3200, "--warmup", 0, "--steps", 900, "--rebalance-every", 150])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["particles_conserved"] is True and rec["rebalanced"] >= 3 and "lean step" in rec["host"]
+    assert rec["max_owned"] <= 6400 // 3 + 700
 
 
 @pytest.mark.gpu
