@@ -512,7 +512,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles * SCAN_SPREAD); ALLOC(a.bcell_start, pad); ALLOC(a.bnear, pad);
     ALLOC(a.dirty, tiles);
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
-    ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_COUNT); ALLOC(a.dn, 4); ALLOC(a.dyn, DYN_COUNT);
+    ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_WORDS); ALLOC(a.dn, 4); ALLOC(a.dyn, DYN_COUNT);
     ALLOC(a.gbar, (size_t)GBAR_WORDS * GBAR_STRIDE);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 1024);
     ALLOC(ctx->d_ids, n);
@@ -540,7 +540,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.block_sums, 0, tiles * SCAN_SPREAD * sizeof(uint32_t), st));
-    HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_COUNT * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_WORDS * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.gbar, 0, sizeof(uint32_t) * (size_t)GBAR_WORDS * GBAR_STRIDE, st));
     a.rebuild = a.flags + FLAG_REBUILD;
     a.check = a.flags + FLAG_CHECK;

@@ -160,7 +160,8 @@ enum {
     FLAG_CHECK_DONE = 29,   // check jobs of the running density launch that have finished (spec_check_job; k_rebuild clears it)
     FLAG_SAVED_WORD = 30,   // sph_time_kernel(SPH_K_DENSITY_SPEC): the rebuild word as it was before the timed launches
     FLAG_HEAD_DONE = 31,    // push blocks of k_slab_head that have finished (grows: the last one of a launch raises the flags)
-    FLAG_COUNT = 32
+    FLAG_COUNT = 32,        // (what the host reads back)
+    FLAG_WORDS = 64
 };
 // Arrays::dyn
 enum {
