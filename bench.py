@@ -115,6 +115,11 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
     k_begin = (ctx.time_kernel("density_eos", PRE_REPS), ctx.time_kernel("force_kick", PRE_REPS), spec_ms(50)) if warmup > 0 and not load_state else None
     rates, rebuilt = [], []
     v_begin, why_begin = ctx.verify_stats(), ctx.rebuild_reasons()
+    try:
+        rep_begin = ctx.repair_stats()
+    except AttributeError:      # (an older build of the library: A/B runs)
+        rep_begin = (0, 0, 0, 0)
+        ctx.repair_stats = lambda: (0, 0, 0, 0)
     for _ in range(windows):
         r0, _d = ctx.rebuild_stats()
         t0 = time.perf_counter()
@@ -125,6 +130,7 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
         rates.append(steps / dt)
         rebuilt.append((r1 - r0) / max(steps, 1))
     verified = (ctx.verify_stats() - v_begin) / max(steps * windows, 1)
+    repairs = [a_ - b_ for a_, b_ in zip(ctx.repair_stats(), rep_begin)]
     why = [a_ - b_ for a_, b_ in zip(ctx.rebuild_reasons(), why_begin)]
     mid = int(np.argsort(rates)[len(rates) // 2])          # the median window (its own rebuild rate goes with it)
     kt = ctx.profile_steps(profile_steps, *(grav.sample(sim[0] * dt_sim) if grav else (0.0, -9.81)))      # HIP events on the kernels' own stream
@@ -154,7 +160,7 @@ def run_single(sph, name, steps, warmup, profile_steps=20, skin=None, tilt=False
            "mparticle_steps_per_s": rates[mid] * n / 1e6, "kernel_ms": kt,
            "max_rho": max_rho, "max_speed": max_speed, "create_s": create_s, "skin_frac": float(prm.skin),
            "skin_min_frac": float(min(prm.skin_min, prm.skin)), "skin_now": ctx.current_skin(),
-           "verified_pairs_per_step": verified, "rebuild_requests": why,
+           "verified_pairs_per_step": verified, "rebuild_requests": why, "list_repairs": repairs,
            "rebuilds": rebuilds, "direct_tiles": direct_tiles, "timed_rebuilds_per_step": rebuilt[mid],
            "window_steps_per_s": [round(x, 2) for x in rates], "window_rebuilds_per_step": [round(x, 4) for x in rebuilt],
            "windows": windows, "window_steps": steps, "warmup": warmup,
@@ -818,6 +824,9 @@ def main():
         # pairs of box groups checked particle by particle per step instead of rebuilding, and who asked for the rebuilds of the
         # timed region: [box pairs that could not be verified, verification found a missing pair, drift cap, rest mode]
         "verified_group_pairs_per_step": round(res["verified_pairs_per_step"], 1), "rebuild_requests": res["rebuild_requests"],
+        # pairs appended to the lists in the timed region instead of a rebuild, and repairs that were not possible: [done, partner not
+        # staged within reach, no free byte in the lane's rows, queue of repaired tiles full]
+        "list_repairs": res["list_repairs"],
         # (the PMC traffic of the regime the window is in: steps 4000+ = the developed flow; the first ~100 steps = the fluid at
         # rest with the smallest skin — the driver's `--steps 20 --warmup 5`; otherwise the early collapse of steps 100-400)
         "roofline": roofline(sph, res, None if args.workload != "cfg2" else "cfg2_developed" if args.warmup >= 3000 else
@@ -836,7 +845,7 @@ def main():
                 "kernel_ms": {k: (v if isinstance(v, list) else round(v, 5)) for k, v in r["kernel_ms"].items()},
                 "neighbour_rebuilds_per_step": round(r["timed_rebuilds_per_step"], 4),
                 "verified_group_pairs_per_step": round(r["verified_pairs_per_step"], 1), "rebuild_requests": r["rebuild_requests"],
-                "max_speed": round(r["max_speed"], 2), "device_mb": round(r["device_mb"], 1), "direct_tiles": r["direct_tiles"],
+                "list_repairs": r["list_repairs"], "max_speed": round(r["max_speed"], 2), "device_mb": round(r["device_mb"], 1), "direct_tiles": r["direct_tiles"],
                 "step_frac": rf["step_frac"], "step_frac_executed": rf["step_frac_executed"], "roofline": rf}
 
     if not args.no_also and args.workload == "cfg2" and args.skin is None and not args.load_state:

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 6
+#define SPH_ABI_VERSION 7      /* 7 (round 5): the halo buffers' header (update written by the force pass), sph_slab_step + sph_slab_set_peer_links,
+                                 * sph_set_rebuild_launches(ctx, N > 1) = a capped grid, verification on slab contexts */
 
 typedef enum sph_error {
     SPH_OK = 0,
@@ -159,8 +160,18 @@ int   sph_request_rebuild(sph_ctx *ctx);
 int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
 /* Verification of failing box pairs (jobs inside the launch of the density pass of sph_step): mode -1 = automatic (from 500 000
  * particles on, where a rebuild costs far more than checking a few thousand particle pairs), 0 = never (two boxes that have moved
- * more than the skin relative to each other ask for the rebuild), 1 = always.  Single-GPU contexts with skin > 0. */
+ * more than the skin relative to each other ask for the rebuild), 1 = always.  Contexts with skin > 0; a slab context (round 5)
+ * verifies with blocks of its step's head kernel, for the groups whose neighbourhood holds owned particles only (a group that can meet
+ * ghosts keeps the absolute criterion: its partners' boxes are not known before the exchange) — every rank may choose for itself:
+ * the rebuild word is MAX-reduced, so all ranks rebuild in the same steps whoever verifies. */
 int  sph_set_verification(sph_ctx *ctx, int mode);
+/* List repair (round 5; single-GPU contexts whose verification is on, default particle order): a pair that the verification finds
+ * inside the support and in nobody's list is APPENDED to the two lists it is missing from — when its partner is staged within reach
+ * of the lane's window bytes and the lane (or, by half a row, its wave) has room — instead of asking for the rebuild of everything;
+ * the density of the repaired tiles is repeated in the same step.  Exact either way (tests/test_gpu_verlet.py: lists against the
+ * walk over the cell ranges).  mode -1 = automatic: from 4 000 000 particles on (a rebuild of 32 M particles costs 4.2 ms, of 2 M
+ * 0.28 ms; a step with repairs ~10 us), 0 = never, 1 = always.  Counters: sph_diag.h. */
+int  sph_set_list_repair(sph_ctx *ctx, int mode);
 /* total particles clamped into the domain so far (0 in a healthy run) */
 long long sph_out_of_domain_count(sph_ctx *ctx);
 

@@ -71,6 +71,11 @@ int  sph_verify_stats(sph_ctx *ctx, long long *pairs);
  * (too many failing neighbours of one group, the queue full, or a mode without verification), why[1] the verification found a
  * pair missing from the lists, why[2] a particle drifted H + skin from its sort position, why[3] unused (0) */
 int  sph_rebuild_reasons(sph_ctx *ctx, long long why[4]);
+/* list repair (single-GPU contexts, default order): out[0] pairs that the verification found inside the support and in nobody's list
+ * and that were APPENDED to the two lists instead of asking for a rebuild; out[1..3] repairs that were not possible (the rebuild was
+ * asked for after all): the partner not staged within reach of the lane's window bytes / no padding byte left in the lane's rows /
+ * more repaired tiles in one step than the queue holds.  SPH_NO_LIST_REPAIR in the environment at creation switches it off (A/B). */
+int   sph_repair_stats(sph_ctx *ctx, long long out[4]);
 /* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
 int   sph_check_stats(sph_ctx *ctx, long long *checks);
 

@@ -39,7 +39,7 @@ ABI_SYMBOLS = [      # include/sph.h: the drop-in boundary (+ slabs, metaballs)
     "sph_read_particles", "sph_read_accel", "sph_read_boundary", "sph_update_boundary", "sph_set_boundary_velocity", "sph_stats",
     "sph_n_fluid", "sph_n_boundary", "sph_grid_dims", "sph_device_grid", "sph_out_of_domain_count",
     "sph_device_cell", "sph_request_rebuild", "sph_set_rebuild_launches", "sph_get_rebuild_launches", "sph_rebuild_stats",
-    "sph_current_skin", "sph_set_verification",
+    "sph_current_skin", "sph_set_verification", "sph_set_list_repair",
     "sph_upload_state", "sph_upload_accel", "sph_eval_density", "sph_eval_pressure", "sph_eval_accel",
     "sph_set_stream", "sph_device_bytes",
     "sph_render_metaballs",
@@ -50,7 +50,7 @@ ABI_SYMBOLS = [      # include/sph.h: the drop-in boundary (+ slabs, metaballs)
 ]
 DIAG_SYMBOLS = [     # include/sph_diag.h: measurement and diagnostics (bench.py, profiling, tests)
     "sph_profile_steps", "sph_time_kernel", "sph_set_variant",
-    "sph_direct_tile_reasons", "sph_verify_stats", "sph_rebuild_reasons", "sph_check_stats",
+    "sph_direct_tile_reasons", "sph_verify_stats", "sph_rebuild_reasons", "sph_check_stats", "sph_repair_stats",
 ]
 HOST_SYMBOLS = [
     "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",
@@ -469,11 +469,23 @@ class Context:
         skin relative to each other are checked particle by particle inside the launch of the density pass (else they ask for the rebuild)."""
         self._chk(self.L.sph_set_verification(self.h, -1 if mode is None else (1 if mode else 0)))
 
+    def set_list_repair(self, mode):
+        """True / False / None (automatic: from 4 000 000 particles on) — missing pairs appended to the lists instead of a rebuild."""
+        self.L.sph_set_list_repair.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.L.sph_set_list_repair(self.h, -1 if mode is None else (1 if mode else 0)))
+
     def rebuild_reasons(self):
         """(unverifiable box pairs, verification found a missing pair, drift cap, unused) — requests for a rebuild so far."""
         a = (C.c_longlong * 4)()
         self._chk(self.L.sph_rebuild_reasons(self.h, a))
         return tuple(int(v) for v in a)
+
+    def repair_stats(self):
+        """(pairs appended to the lists instead of a rebuild, not staged in reach, no free byte, queue full) so far."""
+        a = (C.c_longlong * 4)()
+        self.L.sph_repair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        self._chk(self.L.sph_repair_stats(self.h, a))
+        return tuple(int(x) for x in a)
 
     def verify_stats(self):
         """pairs of box groups verified particle by particle so far (instead of asking for a rebuild)."""

@@ -67,6 +67,7 @@ struct sph_ctx {
     bool one_launch_asked = false;  // sph_set_rebuild_launches(ctx, 1): the host vouches that nothing else computes on the device meanwhile
     bool counted = false;        // this context is in g_live_contexts
     bool deterministic = false;  // particles of a cell in id order (sph_set_deterministic)
+    int repair_mode = -1;        // list repair (sph_set_list_repair): -1 = from REPAIR_MIN_PARTICLES on, 0 = never, 1 = always (default order only)
     hipEvent_t ev[SPH_K_COUNT + 2] = {};
     long long oob_total = 0, nan_total = 0;
     std::string err;
@@ -200,8 +201,14 @@ void refresh_velt(sph_ctx *ctx) {
 //     force + kick + the next step's kick 1/2 + drift (FORCE_KICK_DRIFT), which leaves the displacement boxes for the next check.
 //   The legacy order (ev != nullptr: the profiled step, an event before each kernel in SPH_K_* order; contexts that may share
 //   their device; the direct variant): k_check [+ k_verify], the rebuild as one kernel per phase, density, force.
+constexpr int REPAIR_MIN_PARTICLES = 4000000;     // list repair instead of a rebuild (list_add, sph_list.inc): from this many particles on (sph_set_list_repair)
 constexpr int VERIFY_MIN_PARTICLES = 500000;      // the verify jobs of the density launch: from this many particles on (sph_set_verification)
 bool speculative(const sph_ctx *ctx) { return !ctx->slab && fused(ctx) && ctx->rebuild_wgs > 0; }
+// slab contexts: failing boxes verified particle by particle by blocks of the head kernel (k_slab_head), from the same size on.  Every
+// rank of a run decides alike: the size is the slab's capacity class... no — its own particle count differs from rank to rank, and a
+// rank that verifies rebuilds less often than one that does not: all ranks still rebuild in the same steps (the word is MAX-reduced),
+// so the results do not depend on who verifies; sph_set_verification makes it explicit.
+bool slab_verifies(const sph_ctx *ctx) { return fused(ctx) && (ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0); }
 void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (speculative(ctx) && !ev) {
@@ -347,6 +354,32 @@ int resort_state(sph_ctx *ctx) {
     return SPH_OK;
 }
 
+// what the rebuild-criterion jobs read (SpecJobs, sph_internal.h), one record per orientation of the two position / velocity sets:
+// at creation, and again when a slab adopts a rebuild word of its host's
+int upload_jobs(sph_ctx *ctx) {
+    Arrays &a = ctx->a;
+    if (!a.djobs[0]) return SPH_OK;
+    float2 *const first = a.pos_first, *const other = a.pos == a.pos_first ? a.pos2 : a.pos;
+    float2 *const vfirst = a.pos == a.pos_first ? a.vel : a.vel2, *const vother = a.pos == a.pos_first ? a.vel2 : a.vel;
+    // (list repair: single-GPU contexts in their default order — appended entries land where the races of the verify waves put them:
+    // not for a context that promises the same bits every run)
+    // From REPAIR_MIN_PARTICLES on by default.  What a repair costs does not depend on the size of the scene — the gate repeats the density
+    // of the repaired tiles, ~10 us in a step that has any — what it saves does: a rebuild of 2 M particles is 280 us, of 32 M 4.2 ms.
+    // Measured (tools/ab_env5.sh, same box): cfg4's developed flow 458 -> 583 steps/s (rebuilds in 17 % -> 6 % of the steps); cfg2's
+    // collapse (steps 1200-2200, repairs in nearly every step) 8 660 -> 7 940, its other windows unchanged.
+    const bool repair = !ctx->deterministic && !ctx->slab && (ctx->repair_mode < 0 ? ctx->n >= REPAIR_MIN_PARTICLES : ctx->repair_mode > 0);
+    uint32_t *rq = repair ? a.rq : nullptr;
+    const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, first, a.pos_ref, vfirst, a.uref,
+                         a.tiles, a.nlist, a.stab, a.xranges, rq, a.xpair};
+    SpecJobs j1 = j0;
+    j1.pos = other;
+    j1.vel = vother;
+    HIPCHK(ctx, hipMemcpyAsync(a.djobs[0], &j0, sizeof j0, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(a.djobs[1], &j1, sizeof j1, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // (locals)
+    return SPH_OK;
+}
+
 int check_flags(sph_ctx *ctx) {
     uint32_t h[FLAG_COUNT] = {0};
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -458,6 +491,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     if (make_consts(*prm, ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "invalid parameters (skin must be within [0, 1]) or grid too large");
     if (prm->deterministic != 0 && prm->deterministic != 1) return fail(ctx, SPH_E_ARG, "sph_params.deterministic must be 0 or 1");
     ctx->deterministic = prm->deterministic == 1;
+    if (getenv("SPH_NO_LIST_REPAIR")) ctx->repair_mode = 0;      // (A/B measurements: tools/ab_env5.sh)
+    else if (getenv("SPH_LIST_REPAIR")) ctx->repair_mode = 1;
     ctx->skin = ctx->c.cell - 2 * prm->h;
     if (slab) {
         Consts &c = ctx->c;
@@ -499,15 +534,18 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     const size_t ntiles = ((n + SPH_TILE_PARTICLES - 1) / SPH_TILE_PARTICLES + 8 * XCD_CHUNKS - 1) / (8 * XCD_CHUNKS) * (8 * XCD_CHUNKS) + 9;
     ALLOC(a.tiles, TILE_WORDS * ntiles); ALLOC(a.nlist, (size_t)LIST_WORDS_PER_TILE * ntiles);
     ALLOC(a.lrec, ntiles * SPH_TILE_PARTICLES); ALLOC(a.stab, (size_t)STAB_ENTRIES_PER_TILE * ntiles);
+    ALLOC(a.xpair, ntiles * SPH_TILE_PARTICLES);      // (written by the list build next to lrec; read by the list repair: single-GPU contexts)
     ALLOC(a.xranges, (size_t)XRANGE_WORDS * ntiles);
     ALLOC(a.tstart, 4 * (ntiles + 1)); ALLOC(a.pext, (size_t)ctx->c.cols + 4);
     const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / BOXG);      // box groups
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     a.vq = nullptr;
-    if (!slab) { ALLOC(a.vq, 2 + 2 * (size_t)VQ_CAP); }
+    ALLOC(a.vq, 2 + 2 * (size_t)VQ_CAP);      // (slab contexts too: the verification blocks of their head kernel, k_slab_head)
+    a.rq = nullptr;
+    if (!slab) { ALLOC(a.rq, RQ_CAP); }
     a.djobs[0] = a.djobs[1] = nullptr;
     a.pos_first = a.pos;
-    if (!slab) { ALLOC(a.djobs[0], 1); ALLOC(a.djobs[1], 1); }
+    ALLOC(a.djobs[0], 1); ALLOC(a.djobs[1], 1);
     ALLOC(a.slot, n > nb ? n : nb);
     ALLOC(a.count, pad); ALLOC(a.cell_start, pad); ALLOC(a.block_sums, tiles * SCAN_SPREAD); ALLOC(a.bcell_start, pad); ALLOC(a.bnear, pad);
     ALLOC(a.dirty, tiles);
@@ -520,10 +558,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     uint32_t *&bkey = ctx->d_bkey;
     ALLOC(bpos_in, nb); ALLOC(bvel_in, nb); ALLOC(bkey, nb); ALLOC(ctx->d_bpsi0, nb); ALLOC(ctx->d_bcell_ids, nb);
     a.send[0] = a.send[1] = a.recv[0] = a.recv[1] = nullptr;
-    a.head_arrive = nullptr;
     if (slab) {
-        ALLOC(a.head_arrive, (size_t)2048 * 32);      // (k_slab_head: GATED_GRID_MAX check blocks x HEAD_STRIDE words)
-        HIPCHK(ctx, hipMemsetAsync(a.head_arrive, 0, sizeof(uint32_t) * (size_t)2048 * 32, ctx->stream));
         ctx->halo_bytes = sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * slab->halo_cap);
         for (int k = 0; k < 2; k++) { ALLOC(a.send[k], ctx->halo_bytes / 4); ALLOC(a.recv[k], ctx->halo_bytes / 4); }
         ctx->own_halo = true;
@@ -561,15 +596,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         a.uref = ctx->slab ? nullptr : a.dyn + DYN_UREF_X;      // (slabs: the absolute criterion — their references would differ)
         HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
         if (a.vq) HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (2 + 2 * (size_t)VQ_CAP), st));
-        if (a.djobs[0]) {
-            const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, a.pos, a.pos_ref, a.vel, a.uref};
-            SpecJobs j1 = j0;
-            j1.pos = a.pos2;
-            j1.vel = a.vel2;
-            HIPCHK(ctx, hipMemcpyAsync(a.djobs[0], &j0, sizeof j0, hipMemcpyHostToDevice, st));
-            HIPCHK(ctx, hipMemcpyAsync(a.djobs[1], &j1, sizeof j1, hipMemcpyHostToDevice, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));      // (locals)
-        }
+        if ((rc = upload_jobs(ctx)) != SPH_OK) return rc;
     }
 
     // boundary: bin once, pseudo-mass once (:600-601)
@@ -872,12 +899,20 @@ int sph_direct_tile_reasons(sph_ctx *ctx, long long why[7]) {
 }
 int sph_set_verification(sph_ctx *ctx, int mode) {
     if (!ctx || !ctx->stream || mode < -1 || mode > 1) return SPH_E_ARG;
-    if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_set_verification: single-GPU contexts only");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->verify_mode = mode;
     drop_graph(ctx);      // (an argument of the captured density launches)
     return SPH_OK;
+}
+
+int sph_set_list_repair(sph_ctx *ctx, int mode) {
+    if (!ctx || !ctx->stream || mode < -1 || mode > 1) return SPH_E_ARG;
+    if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_set_list_repair: single-GPU contexts only");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->repair_mode = mode;
+    return upload_jobs(ctx);
 }
 
 int sph_rebuild_reasons(sph_ctx *ctx, long long why[4]) {
@@ -887,6 +922,17 @@ int sph_rebuild_reasons(sph_ctx *ctx, long long why[4]) {
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags + FLAG_WHY_REBUILD, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 4; k++) why[k] = h[k];
+    return SPH_OK;
+}
+
+int sph_repair_stats(sph_ctx *ctx, long long out[4]) {
+    if (!ctx || !ctx->stream || !out) return SPH_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    uint32_t h[4] = {0, 0, 0, 0};
+    static_assert(FLAG_REPAIR_FAIL == FLAG_REPAIRS + 1, "read as one block");
+    HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags + FLAG_REPAIRS, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; k++) out[k] = h[k];
     return SPH_OK;
 }
 
@@ -1137,7 +1183,11 @@ int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
     }
     ctx->primed = fused(ctx);
     const float gravity[2] = {gx, gy};
-    launch_check(st, ctx->c, ctx->a, ctx->cap, gravity);      // beyond skin/2 somewhere: compare the boxes; may raise the rebuild word
+    // beyond skin/2 somewhere: compare the boxes, verify the failing ones particle by particle; may raise the rebuild word
+    PeerHead none = {};
+    none.nranks = 1;
+    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, none, slab_verifies(ctx));
+    ctx->lean_step++;      // (the device counts the same steps: the tags of the lean step's messages, should the host switch to it)
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_phase = 1;
     return SPH_OK;
@@ -1268,7 +1318,7 @@ int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
         }
     }
     const float gravity[2] = {gx, gy};
-    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph);                                            // 1
+    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph, slab_verifies(ctx));                        // 1
     launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 3 : 1, peer ? &pl : nullptr);   // 2
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, DENS_ALL, false);       // 3
     launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);                            // 4
@@ -1301,7 +1351,7 @@ int sph_slab_set_flag_buffer(sph_ctx *ctx, void *dev_word) {
     ctx->a.rebuild = dev_word ? static_cast<uint32_t *>(dev_word) : ctx->a.flags + FLAG_REBUILD;
     HIPCHK(ctx, hipMemsetAsync(ctx->a.rebuild, 0, sizeof(uint32_t), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return SPH_OK;
+    return upload_jobs(ctx);      // (the criterion's jobs of the head kernel raise the word: they must know where it is)
 }
 
 int sph_slab_flag_get(sph_ctx *ctx, uint32_t *value) {

@@ -69,6 +69,16 @@ struct SpecJobs {
     const float2 *pos, *pos_ref;
     const float2 *vel;      // (pos and vel of ONE orientation of the two sets)
     float *uref;            // the reference displacement of this step's force pass (sample_uref; null: the absolute criterion)
+    // list repair (round 5; null rq: off — slab contexts, the deterministic order): a pair the verification finds inside the support
+    // and in nobody's list is APPENDED to both lists instead of asking for the rebuild (list_add, sph_list.inc)
+    uint32_t *tiles;        // TileInfo records
+    uint32_t *nlist;
+    const unsigned short *stab;
+    const uint32_t *xranges;
+    uint32_t *rq;           // tiles whose lists were repaired in this step: the gate repeats their density (RQ_CAP entries)
+    uint2 *xpair;           // per tile lane (like lrec): up to two partners (sorted indices) of pairs this lane's particle was repaired
+                            // with since the last rebuild (0xffffffff: none) — how the verification of the following steps knows, from one
+                            // coalesced load, the pairs it has dealt with (they break its rule "listed exactly if within the cut-off then")
 };
 
 struct Arrays {
@@ -121,13 +131,14 @@ struct Arrays {
                         // that it MAX-reduces over all ranks between kick/drift and the halo pack
     SpecJobs *djobs[2]; // see SpecJobs (single-GPU contexts): [0] with pos = pos_first, [1] with the alternate set (filled once at creation)
     float2 *pos_first;  // what pos pointed at when the context was created
+    uint32_t *rq;       // tiles whose lists this step's verification repaired (SpecJobs::rq; RQ_CAP entries; nullptr: no repairs)
+    uint2 *xpair;       // SpecJobs::xpair (reset by the list build; nullptr: no repairs)
     uint32_t *vq;       // verification queue (spec_check_job -> spec_verify_job): [0] count, [2 + 2 e ..] = (group, failing neighbour group); nullptr: slabs
     float *uref;        // where the density pass leaves the reference displacement (dyn + DYN_UREF_X; nullptr: slab contexts)
     float *dyn;         // DYN_COUNT floats: the list cut-off and the rebuild thresholds that follow from the current skin
     uint32_t *dn;       // live counts: [0] particles in the sorted/staging arrays, [1] owned particles after kick/drift
     // slab halo buffers: uint32 header[4] (HALO_*) + halo_cap records of 5 words (x, y, u, v, id)
     uint32_t *send[2], *recv[2];   // [0] = left neighbour, [1] = right neighbour
-    uint32_t *head_arrive;         // slab contexts: one arrival word per check block of k_slab_head, HEAD_STRIDE words apart
 };
 
 enum {
@@ -161,6 +172,11 @@ enum {
     FLAG_SAVED_WORD = 30,   // sph_time_kernel(SPH_K_DENSITY_SPEC): the rebuild word as it was before the timed launches
     FLAG_HEAD_DONE = 31,    // push blocks of k_slab_head that have finished (grows: the last one of a launch raises the flags)
     FLAG_COUNT = 32,        // (what the host reads back)
+    FLAG_VERIFY_DONE = 32,  // verify blocks of the running k_slab_head that have finished (the launch after it clears it)
+    FLAG_NREPAIR = 33,      // tiles queued in Arrays::rq by this step's list repairs (the first check job of the next density launch clears it)
+    FLAG_REPAIRS = 34,      // pairs appended to the lists so far instead of a rebuild (list_add: two entries each)
+    FLAG_REPAIR_FAIL = 35,  // + k: repairs that were not possible and asked for the rebuild after all: (0) the partner is not staged within
+                            //   reach of the lane's window bytes, (1) no free byte in the lane's rows, (2) the queue of repaired tiles is full
     FLAG_WORDS = 64
 };
 // Arrays::dyn
@@ -203,6 +219,7 @@ constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle lis
 #define SPH_VQ_CAP 4096
 #endif
 constexpr int VQ_CAP = SPH_VQ_CAP;    // pairs of groups the verification queue holds (more: rebuild)
+constexpr int RQ_CAP = 2048;          // tiles one step's list repairs may queue for a repeat of their density (more: rebuild)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer (below)
 constexpr int HALO_REC = 5;     // words per halo record
 // the header: [0] particles in the UPDATE message {x, y, u, v} and [1] the step it is for — written by the kernel that drifted the
@@ -247,7 +264,7 @@ struct PeerLinks {     // k_rebuild_slab, lean: wait for the update | exchange t
     const uint32_t *my_flag_l, *my_flag_r;           // this rank's own arrival flags (what its neighbours raise)
     uint32_t step;
 };
-void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph);
+void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph, bool verify);
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag);
 void launch_peer_push(hipStream_t st, const Consts &c, const Arrays &a, void *remote_l, void *flag_l, void *remote_r, void *flag_r, uint32_t tag);
 void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const void *flag_r, uint32_t tag);

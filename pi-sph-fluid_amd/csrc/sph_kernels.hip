@@ -703,8 +703,13 @@ __global__ __launch_bounds__(BLK) void k_halo_in(Consts c, const uint32_t *__res
                                                  uint32_t *__restrict__ flags, const uint32_t *__restrict__ rebuild,
                                                  uint32_t *__restrict__ dn, int stage_cap, float2 *__restrict__ pos,
                                                  float2 *__restrict__ vel, const uint32_t *__restrict__ cs, int halo_blocks,
-                                                 uint32_t *__restrict__ block_sums) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags[FLAG_LATCH] = *rebuild;      // for the final density pass (DENS_REST)
+                                                 uint32_t *__restrict__ block_sums, uint32_t *__restrict__ vq) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        flags[FLAG_LATCH] = *rebuild;      // for the final density pass (DENS_REST)
+        flags[FLAG_CHECK_DONE] = 0u;       // (the criterion's blocks of this step's head kernel: k_slab_head)
+        flags[FLAG_VERIFY_DONE] = 0u;
+        if (vq) vq[0] = 0u;
+    }
     if (*rebuild != 0u) {
         ingest_body(c, recv_l, recv_r, velk, pk, slot, count, dirty, flags, dn, stage_cap, block_sums, (int)blockIdx.x);
     } else {
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(BLK) void k_halo_in(Consts c, const uint32_t *__res
 void launch_halo_in(hipStream_t st, const Consts &c, const Arrays &a, int stage_cap) {
     const int halo_blocks = (c.halo_cap + BLK - 1) / BLK > 0 ? (c.halo_cap + BLK - 1) / BLK : 1;
     hipLaunchKernelGGL(k_halo_in, dim3(2 * halo_blocks), dim3(BLK), 0, st, c, a.recv[0], a.recv[1], a.velk, a.pk, a.slot,
-                       a.count, a.dirty, a.flags, a.rebuild, a.dn, stage_cap, a.pos, a.vel, a.cell_start, halo_blocks, a.block_sums);
+                       a.count, a.dirty, a.flags, a.rebuild, a.dn, stage_cap, a.pos, a.vel, a.cell_start, halo_blocks, a.block_sums, a.vq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1174,98 +1179,6 @@ __global__ __launch_bounds__(64) void k_peer_wait(const uint32_t *__restrict__ f
     if (threadIdx.x == 0 && flag_l) (void)peer_wait(flag_l, tag, 0u, flags, v);
     if (threadIdx.x == 1 && flag_r) (void)peer_wait(flag_r, tag, 0u, flags, v);
 }
-// ---- the lean slab step (round 5): the head of a step as ONE launch ----
-// k_check (count the step, this step's gravity, the record half of the send headers, the boxes when somebody is beyond skin/2)
-// and — peer transport — what used to be two more launches: the push of this step's UPDATE message, which the last force pass
-// left in the send buffers, into the neighbours' receive buffers of this step's parity (then their arrival flags: tag 2 x step),
-// and the MAX of the rebuild word over the ranks.  Block order: [check blocks][push blocks][one exchange block]; the exchange
-// block is dispatched last and waits (bounded) for the check blocks' arrival words when there were boxes to compare.
-// The receive buffers are double-buffered by step parity: a neighbour's unpack of step t reads parity t & 1 while this rank,
-// a launch ahead, may already push step t + 1; parity t & 1 is written again in step t + 2, whose head follows this rank's
-// wait for that neighbour's step-t+1 message, which that neighbour pushed after its unpack of step t.
-constexpr int HEAD_PUSH_WGS = 16, HEAD_STRIDE = 32;      // (arrival words 128 bytes apart)
-__global__ __launch_bounds__(BLK) void k_slab_head(Consts c, const float4 *__restrict__ wbox, const uint32_t *__restrict__ wnbr,
-                                                   const uint32_t *__restrict__ cs, const uint32_t *__restrict__ check,
-                                                   uint32_t *__restrict__ rebuild, uint32_t *__restrict__ flags,
-                                                   const uint32_t *__restrict__ dn, uint32_t *__restrict__ send_l,
-                                                   uint32_t *__restrict__ send_r, int nw, float2 *__restrict__ grav, float gx, float gy,
-                                                   const float *__restrict__ dyn, PeerHead ph, uint32_t *__restrict__ arrive,
-                                                   int ncheck, int npush) {
-    const int b = (int)blockIdx.x;
-    if (b < ncheck) {
-        const bool worked = check_body(c, wbox, wnbr, cs, check, rebuild, flags, dn, send_l, send_r, nw, grav, gx, gy, dyn, b, ncheck);
-        if (worked && ph.nranks > 1) {      // this block's verdict is in: tell the exchange block
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_store(arrive + (size_t)b * HEAD_STRIDE, ph.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        return;
-    }
-    if (b < ncheck + npush) {      // this step's update message -> the neighbours (header rewritten: the record half is not this kernel's to copy)
-        const int pb = b - ncheck;
-        for (int side = 0; side < 2; side++) {
-            const uint32_t *src = side == 0 ? send_l : send_r;
-            uint32_t *dst = side == 0 ? ph.remote_l : ph.remote_r;
-            if (!dst) continue;
-            const uint32_t count = min(src[HALO_UPD_COUNT], (uint32_t)c.halo_cap);
-            if (pb == 0 && threadIdx.x == 0) reinterpret_cast<uint4 *>(dst)[0] = make_uint4(count, src[HALO_UPD_STEP], 0u, 0u);
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + HALO_HDR);
-            uint4 *d4 = reinterpret_cast<uint4 *>(dst + HALO_HDR);
-            for (uint32_t k = (uint32_t)pb * BLK + threadIdx.x; k < count; k += (uint32_t)npush * BLK) d4[k] = s4[k];
-        }
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t arrived = atomicAdd(&flags[FLAG_HEAD_DONE], 1u);      // (grows by npush per launch: never reset)
-            if ((arrived + 1u) % (uint32_t)npush == 0u) {
-                __threadfence_system();
-                if (ph.flag_l) __hip_atomic_store(ph.flag_l, 2u * ph.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (ph.flag_r) __hip_atomic_store(ph.flag_r, 2u * ph.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        return;
-    }
-    // the exchange block: the MAX of the rebuild word over the ranks (k_peer_reduce), once every check block has spoken
-    __shared__ uint32_t s_ok;
-    if (threadIdx.x == 0) s_ok = 1u;
-    __syncthreads();
-    if (*check != 0u) {
-        for (int w = (int)threadIdx.x; w < ncheck; w += BLK) {
-            uint32_t spins = 0u;
-            while (__hip_atomic_load(arrive + (size_t)w * HEAD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ph.step) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 22)) { s_ok = 0u; atomicOr(&flags[FLAG_BAR_TIMEOUT], 1u); break; }
-            }
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    if (threadIdx.x >= 64u) return;
-    const int q = (int)threadIdx.x;
-    const uint32_t par = (ph.step & 1u) * (uint32_t)SPH_PEER_MAX_RANKS;
-    const uint32_t w = s_ok ? __hip_atomic_load(rebuild, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)REBUILD_CRITERION;
-    uint32_t got = w;
-    if (q < ph.nranks && q != ph.me) {
-        __hip_atomic_store(ph.slots_of_rank[q] + par + (uint32_t)ph.me, (ph.step << 2) | (w & 3u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        uint32_t v = 0u;
-        if (peer_wait(ph.my_slots + par + (uint32_t)q, ph.step, 2u, flags, v)) got = v & 3u;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) got = max(got, (uint32_t)__shfl_xor((int)got, d, 64));
-    if (q == 0) *rebuild = got;
-}
-void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph) {
-    if (cap <= 0) return;
-    const int nw = (cap + BOXG - 1) / BOXG;
-    const int ncheck = gated_grid((nw * CHECK_LANES + BLK - 1) / BLK);
-    const int npush = (ph.remote_l || ph.remote_r) ? HEAD_PUSH_WGS : 0, nxchg = ph.nranks > 1 ? 1 : 0;
-    hipLaunchKernelGGL(k_slab_head, dim3(ncheck + npush + nxchg), dim3(BLK), 0, st, c, a.wbox, a.wnbr, a.cell_start, a.check, a.rebuild,
-                       a.flags, a.dn, a.send[0], a.send[1], nw, a.grav, gravity[0], gravity[1], a.dyn, ph, a.head_arrive, ncheck, npush);
-}
-
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag) {
     PeerSlots ps;
     for (int q = 0; q < SPH_PEER_MAX_RANKS; q++) ps.of_rank[q] = q < nranks ? static_cast<uint32_t *>(slots_of_rank[q]) : nullptr;

@@ -107,10 +107,17 @@ def test_slab_reuses_lists_between_rebuilds(sph, orc):
     prm = sph.default_params(tuple(g["box"]))
     f = particles(orc, g["state"], np.float32(prm.rho0) * np.float32(prm.vol))      # developed flow, |v| up to 20 m/s
     b = boundary_particles(orc, g["boundary_xy"])
+    import ctypes as C
+    L = sph.hip_lib()
+    saved = {}
     if True:
-        for frac in (0.0, 0.2):
+        # (frac, verify): verify = the slabs check failing displacement boxes particle by particle (blocks of their head kernel,
+        # round 5; automatic from 500 000 particles per slab on) instead of rebuilding: fewer rebuilds, the same gates
+        for frac, verify in ((0.0, False), (0.2, False), (0.2, True)):
             prm.skin = prm.skin_min = frac          # per context: the slabs and the single context below all get this skin
             slabs, runner = build(sph, prm, f, b, 3)
+            for s in slabs:
+                assert L.sph_set_verification(s.h, 1 if verify else 0) == 0
             with sph.Context(prm, f, b, GX, GY) as ctx:
                 ctx.step(20, GX, GY)
                 ctx.sync()
@@ -131,17 +138,21 @@ def test_slab_reuses_lists_between_rebuilds(sph, orc):
             # summation order only, amplified by the chaotic developed flow (as in test_developed_block_slabs_vs_single)
             assert max(np.abs(out["x"] - ref["x"]).max(), np.abs(out["y"] - ref["y"]).max()) <= 2e-3, frac
             assert np.max(np.abs(out["rho"] - ref["rho"]) / ref["rho"]) <= 2e-2, frac
-            L = sph.hip_lib()
-            import ctypes as C
-            counts = []
+            counts, verified = [], 0
             for s in slabs:
                 a, d = C.c_longlong(), C.c_longlong()
                 assert L.sph_rebuild_stats(s.h, C.byref(a), C.byref(d)) == 0
                 counts.append(a.value)
+                v = C.c_longlong()
+                assert L.sph_verify_stats(s.h, C.byref(v)) == 0
+                verified += v.value
             assert len(set(counts)) == 1, counts                      # all slabs rebuilt in the same steps
             assert (counts[0] - 1 == 120) if frac == 0.0 else (1 < counts[0] - 1 < 120), (frac, counts)
+            assert (verified > 0) == verify, (frac, verify, verified)
+            saved[(frac, verify)] = counts[0]
             for s in slabs:
                 s.close()
+    assert saved[(0.2, True)] < saved[(0.2, False)], saved            # verification saved rebuilds
 
 
 def test_step_overlap_is_optional(sph, orc):

@@ -217,17 +217,21 @@ def test_c_host_lean_step_updates_equal_the_three_call_step_bitwise(sph, tmp_pat
     Three ranks, 400 steps, deterministic order: the same bits as the three-call step over the same transport (which packs
     nothing either any more, but pushes and waits with kernels of its own) — and re-balancing on top (contexts re-created, the
     peer blocks and their flags kept) ends cleanly with every particle owned once."""
-    states = []
-    for lean in (1, 0):
-        state = tmp_path / ("state%d.bin" % lean)
-        r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", lean, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
-                                 "--velocity", 5, 0, "--steps", 300, "--warmup", 100, "--deterministic", "--dump-state", state])
-        assert r.returncode == 0, r.stderr.decode()[-3000:]
-        assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200 and ("lean step" in rec["host"]) == bool(lean)
-        states.append((np.fromfile(state, sph.PARTICLE), rec["neighbour_rebuilds"]))
-    assert states[0][1] == states[1][1]                                  # the ranks rebuilt in the same steps
-    for k in ("x", "y", "u", "v", "rho", "p"):
-        assert np.array_equal(states[0][0][k], states[1][0][k]), k
+    rebuilds = {}
+    for verify in (1, 0):      # (1: failing boxes verified particle by particle by blocks of the head kernel — automatic from 500 000 particles per slab on)
+        states = []
+        for lean in (1, 0):
+            state = tmp_path / ("state%d%d.bin" % (lean, verify))
+            r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", lean, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
+                                     "--velocity", 5, 0, "--steps", 300, "--warmup", 100, "--deterministic", "--verify", verify, "--dump-state", state])
+            assert r.returncode == 0, r.stderr.decode()[-3000:]
+            assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200 and ("lean step" in rec["host"]) == bool(lean)
+            states.append((np.fromfile(state, sph.PARTICLE), rec["neighbour_rebuilds"]))
+        assert states[0][1] == states[1][1]                                  # the ranks rebuilt in the same steps
+        for k in ("x", "y", "u", "v", "rho", "p"):
+            assert np.array_equal(states[0][0][k], states[1][0][k]), (k, verify)
+        rebuilds[verify] = states[0][1]
+    assert rebuilds[1] <= rebuilds[0]                                        # verification only ever saves rebuilds
     # re-balancing under the lean step: the block of test_c_host_rebalancing_..., flying along x at 30 m/s out of the first slab and
     # into the last — the contexts are re-created (their step counts, the tags of the lean step's messages, start from 1 again:
     # the flags and word slots of the peer blocks with them)
