@@ -160,12 +160,13 @@ int   sph_request_rebuild(sph_ctx *ctx);
 int   sph_rebuild_stats(sph_ctx *ctx, long long *rebuilds, long long *direct_tiles);
 /* Verification of failing box pairs (jobs inside the launch of the density pass of sph_step): mode -1 = automatic (from 500 000
  * particles on, where a rebuild costs far more than checking a few thousand particle pairs), 0 = never (two boxes that have moved
- * more than the skin relative to each other ask for the rebuild), 1 = always.  Contexts with skin > 0; a slab context (round 5)
- * verifies with blocks of its step's head kernel, for the groups whose neighbourhood holds owned particles only (a group that can meet
- * ghosts keeps the absolute criterion: its partners' boxes are not known before the exchange) — every rank may choose for itself:
- * the rebuild word is MAX-reduced, so all ranks rebuild in the same steps whoever verifies. */
+ * more than the skin relative to each other ask for the rebuild), 1 = always.  Contexts with skin > 0.  A slab context (round 5)
+ * verifies only in mode 1 — with blocks of its step's head kernel, which is on the step's critical path (sph_step's jobs ride inside
+ * its density launch): worth it where rebuilds are frequent and expensive — for the groups whose neighbourhood holds owned particles
+ * only (a group that can meet ghosts keeps the absolute criterion: its partners' boxes are not known before the exchange); every
+ * rank may choose for itself: the rebuild word is MAX-reduced, so all ranks rebuild in the same steps whoever verifies. */
 int  sph_set_verification(sph_ctx *ctx, int mode);
-/* List repair (round 5; single-GPU contexts whose verification is on, default particle order): a pair that the verification finds
+/* List repair (round 5; contexts whose verification is on, default particle order): a pair that the verification finds
  * inside the support and in nobody's list is APPENDED to the two lists it is missing from — when its partner is staged within reach
  * of the lane's window bytes and the lane (or, by half a row, its wave) has room — instead of asking for the rebuild of everything;
  * the density of the repaired tiles is repeated in the same step.  Exact either way (tests/test_gpu_verlet.py: lists against the

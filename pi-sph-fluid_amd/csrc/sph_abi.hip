@@ -204,11 +204,12 @@ void refresh_velt(sph_ctx *ctx) {
 constexpr int REPAIR_MIN_PARTICLES = 4000000;     // list repair instead of a rebuild (list_add, sph_list.inc): from this many particles on (sph_set_list_repair)
 constexpr int VERIFY_MIN_PARTICLES = 500000;      // the verify jobs of the density launch: from this many particles on (sph_set_verification)
 bool speculative(const sph_ctx *ctx) { return !ctx->slab && fused(ctx) && ctx->rebuild_wgs > 0; }
-// slab contexts: failing boxes verified particle by particle by blocks of the head kernel (k_slab_head), from the same size on.  Every
-// rank of a run decides alike: the size is the slab's capacity class... no — its own particle count differs from rank to rank, and a
-// rank that verifies rebuilds less often than one that does not: all ranks still rebuild in the same steps (the word is MAX-reduced),
-// so the results do not depend on who verifies; sph_set_verification makes it explicit.
-bool slab_verifies(const sph_ctx *ctx) { return fused(ctx) && (ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0); }
+// Slab contexts: failing boxes verified particle by particle by blocks of the head kernel (k_slab_head) — ONLY when the host asks
+// (sph_set_verification(ctx, 1)).  In sph_step the criterion's jobs ride inside the density launch and cost the step nothing; the slab
+// step's head kernel is on its critical path: measured with one slab through the C host (bench.py, slab_overhead, 2 M particles), the
+// verification made the collapse windows 5 % faster (fewer rebuilds) and every other window 10 - 15 % slower.  Every rank may choose
+// for itself: the rebuild word is MAX-reduced, all ranks rebuild in the same steps whoever verifies.
+bool slab_verifies(const sph_ctx *ctx) { return fused(ctx) && ctx->verify_mode > 0; }
 void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (speculative(ctx) && !ev) {
@@ -367,10 +368,13 @@ int upload_jobs(sph_ctx *ctx) {
     // of the repaired tiles, ~10 us in a step that has any — what it saves does: a rebuild of 2 M particles is 280 us, of 32 M 4.2 ms.
     // Measured (tools/ab_env5.sh, same box): cfg4's developed flow 458 -> 583 steps/s (rebuilds in 17 % -> 6 % of the steps); cfg2's
     // collapse (steps 1200-2200, repairs in nearly every step) 8 660 -> 7 940, its other windows unchanged.
-    const bool repair = !ctx->deterministic && !ctx->slab && (ctx->repair_mode < 0 ? ctx->n >= REPAIR_MIN_PARTICLES : ctx->repair_mode > 0);
-    uint32_t *rq = repair ? a.rq : nullptr;
+    // Slab contexts repair too (the verification blocks of their head kernel, k_slab_head): their density pass runs after the head
+    // kernel, on the repaired lists — there is nothing to repeat and no queue.
+    const bool repair = !ctx->deterministic && (ctx->repair_mode < 0 ? ctx->n >= REPAIR_MIN_PARTICLES : ctx->repair_mode > 0);
+    uint32_t *rq = repair && !ctx->slab ? a.rq : nullptr;
+    const uint32_t repair_kind = !repair ? 0u : ctx->slab ? 2u : 1u;
     const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, first, a.pos_ref, vfirst, a.uref,
-                         a.tiles, a.nlist, a.stab, a.xranges, rq, a.xpair};
+                         a.tiles, a.nlist, a.stab, a.xranges, rq, a.xpair, repair_kind};
     SpecJobs j1 = j0;
     j1.pos = other;
     j1.vel = vother;
@@ -908,7 +912,6 @@ int sph_set_verification(sph_ctx *ctx, int mode) {
 
 int sph_set_list_repair(sph_ctx *ctx, int mode) {
     if (!ctx || !ctx->stream || mode < -1 || mode > 1) return SPH_E_ARG;
-    if (ctx->slab) return fail(ctx, SPH_E_STATE, "sph_set_list_repair: single-GPU contexts only");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->repair_mode = mode;

@@ -75,10 +75,13 @@ struct SpecJobs {
     uint32_t *nlist;
     const unsigned short *stab;
     const uint32_t *xranges;
-    uint32_t *rq;           // tiles whose lists were repaired in this step: the gate repeats their density (RQ_CAP entries)
+    uint32_t *rq;           // tiles whose lists were repaired in this step: the gate repeats their density (RQ_CAP entries); null: no repairs
+                            // — or (rq_none below) a slab context: its density pass runs AFTER the head kernel's repairs, nothing to repeat
     uint2 *xpair;           // per tile lane (like lrec): up to two partners (sorted indices) of pairs this lane's particle was repaired
                             // with since the last rebuild (0xffffffff: none) — how the verification of the following steps knows, from one
                             // coalesced load, the pairs it has dealt with (they break its rule "listed exactly if within the cut-off then")
+    uint32_t repair;        // 0: a missing pair asks for the rebuild; 1: list repair, repaired tiles queued in rq (single-GPU contexts: the
+                            // speculative density pass of the same launch may have read the lists as they were); 2: list repair, no queue
 };
 
 struct Arrays {

@@ -29,7 +29,7 @@
  *   slab_sph_fluid --ranks N [--transport rccl|host|peer] [--scene dam|cfg3|cfg4|cfg4slab] [--block NX NY BOXW BOXH] [--origin X0 Y0]
  *                  [--velocity U V] [--steps K] [--warmup W] [--windows N] [--tilt] [--check] [--deterministic] [--skin F]
  *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE]
- *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--one-launch-wgs N] [--verify -1|0|1]
+ *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--one-launch-wgs N] [--verify -1|0|1] [--repair -1|0|1]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
  * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
  * what may sit under a profiler; the launcher must not: see profiles/README.md).  The ncclUniqueId travels through a file
@@ -419,7 +419,7 @@ typedef struct rank_state {
     int device, transport, deterministic, capacity, halo_capacity;
     int own_device;              /* no other rank of this run on this rank's device (peer: as many devices as ranks) */
     int lean;                    /* the step is ONE call, sph_slab_step: four kernels, the exchange inside them (peer transport, or a slab alone) */
-    int verify;                  /* sph_set_verification: -1 automatic, 0 never, 1 always */
+    int verify, repair;          /* sph_set_verification / sph_set_list_repair: -1 automatic, 0 never, 1 always */
     int one_launch_wgs;          /* > 0: the one-launch kernels of this rank use at most so many workgroups (ranks sharing a device: they must all be resident) */
     sph_particle *walls;
     long nw;
@@ -517,6 +517,7 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
     SPHCHK(rs->ctx, sph_create_slab(&rs->ctx, &rs->prm, &desc, loc, ids, (int)n_loc, rs->walls, (int)rs->nw, gx, gy, rs->device));
     SPHCHK(rs->ctx, sph_set_stream(rs->ctx, rs->st));
     if (rs->verify >= 0) SPHCHK(rs->ctx, sph_set_verification(rs->ctx, rs->verify));
+    if (rs->repair >= 0) SPHCHK(rs->ctx, sph_set_list_repair(rs->ctx, rs->repair));
     /* one rank per GPU (rccl): nothing else computes on this device, so what follows the halo exchange may run as one
      * launch with grid barriers (include/sph.h, sph_set_rebuild_launches); ranks that may share a device must not */
     if (rs->one_launch_wgs > 0) SPHCHK(rs->ctx, sph_set_rebuild_launches(rs->ctx, rs->one_launch_wgs));      /* (a capped grid: ranks that share a device) */
@@ -730,6 +731,7 @@ static int rebalance(rank_state *rs, float gx, float gy, double min_gain, int *m
 int main(int argc, char **argv) {
     int nranks = 1, rank = -1, steps = 200, warmup = 50, windows = 1, tilt = 0, check = 0, deterministic = 0, transport = TR_RCCL;
     int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2, breakdown = 0, halo_capacity = -1;
+    int repair_opt = -1;                        /* --repair -1 (default: from 4 000 000 particles per slab on) | 0 | 1: sph_set_list_repair */
     int verify_opt = -1;                        /* --verify -1 (default: from 500 000 particles per slab on) | 0 | 1: sph_set_verification */
     int lean_opt = -1, one_launch_wgs = 0;      /* --lean auto (-1) | 0 | 1; --one-launch-wgs N: cap of the one-launch kernels' grid (ranks that share a device) */
     float skin = -1;
@@ -763,6 +765,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--lean") && i + 1 < argc) { i++; lean_opt = !strcmp(argv[i], "auto") ? -1 : atoi(argv[i]); }
         else if (!strcmp(argv[i], "--one-launch-wgs") && i + 1 < argc) one_launch_wgs = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--verify") && i + 1 < argc) verify_opt = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--repair") && i + 1 < argc) repair_opt = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--exchange-stream") && i + 1 < argc) { i++; xside = !strcmp(argv[i], "side") ? 1 : !strcmp(argv[i], "main") ? 0 : 2; }
         else if (!strcmp(argv[i], "--deterministic")) deterministic = 1;
         else if (!strcmp(argv[i], "--skin") && i + 1 < argc) skin = (float)atof(argv[++i]);
@@ -873,6 +876,7 @@ int main(int argc, char **argv) {
     rs.own_device = nranks <= ndev;
     rs.one_launch_wgs = one_launch_wgs;
     rs.verify = verify_opt;
+    rs.repair = repair_opt;
     /* The lean step needs the one-launch kernels (the device is this rank's alone, or the ranks that share it cap their grids so
      * that all stay resident) and a transport that lives inside the step's kernels: peer-mapped memory — or no neighbour at all. */
     {
