@@ -307,8 +307,9 @@ int  sph_slab_peer_wait(sph_ctx *ctx, const void *flag_from_left, const void *fl
  * called, or NULL): a slab without neighbours.  The links name memory of the other ranks as mapped into this process
  * (hipIpcOpenMemHandle: the peer-mapped transport above); every rank's block holds TWO receive buffers per side — the message
  * of step t goes to parity t & 1: a neighbour may push step t + 1 while this rank still reads step t — one arrival flag per side
- * (tag 2 t for the update of step t, 2 t + 1 for the records of a rebuild step t) and the slot array of the word exchange.
- * All waits are bounded (SPH_E_STATE at the next call that reads the flags). */
+ * (tag 2 t for the update of step t, 2 t + 1 for the records of a rebuild step t; a flag only grows and a wait is for
+ * "at least": the neighbour's next head kernel may have raised it to 2 (t + 1) already) and the slot array of the word exchange.
+ * All waits are bounded (SPH_E_STATE at the next call that reads the flags; the error string names the wait that gave up first). */
 typedef struct sph_peer_links {
     int   me, n_ranks;
     void *slots_of_rank[SPH_PEER_MAX_RANKS];   /* every rank's slot array uint32[2][SPH_PEER_MAX_RANKS] (entry `me`: this rank's own) */

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -390,9 +391,17 @@ int check_flags(sph_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (h[FLAG_BAR_TIMEOUT]) {
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_BAR_TIMEOUT, 0, sizeof(uint32_t), ctx->stream));
-        if (h[FLAG_BAR_TIMEOUT] & 2u)      // (the peer transport's waits have a bit of their own: nothing is wrong with this rank's launches)
-            return fail(ctx, SPH_E_STATE, "peer transport: a neighbouring rank's rebuild word or halo did not arrive within the time limit (is "
-                                          "every rank stepping? sph_slab_peer_reduce / _wait); the state is invalid, upload it again");
+        if (h[FLAG_BAR_TIMEOUT] & 2u) {      // (the peer transport's waits have a bit of their own: nothing is wrong with this rank's launches)
+            uint32_t d[4] = {0, 0, 0, 0};
+            HIPCHK(ctx, hipMemcpy(d, ctx->a.flags + FLAG_PEER_DIAG, sizeof d, hipMemcpyDeviceToHost));
+            static const char *const site[] = {"?", "rebuild word (sph_slab_peer_reduce), rank", "halo (sph_slab_peer_wait), side", "rebuild word (head of sph_slab_step), rank",
+                                               "ghost update (sph_slab_step), side", "records (sph_slab_step), side"};
+            char buf[384];
+            snprintf(buf, sizeof buf, "peer transport: a neighbouring rank's rebuild word or halo did not arrive within the time limit (is every rank "
+                     "stepping?) - first to give up: the wait for the %s %u, tag 0x%x, word last seen 0x%x, step %u; the state is invalid, upload it again",
+                     site[(d[0] >> 8) < 6u ? (d[0] >> 8) : 0u], d[0] & 255u, d[1], d[2], d[3]);
+            return fail(ctx, SPH_E_STATE, buf);
+        }
         ctx->rebuild_wgs = 0;
         drop_graph(ctx);
         return fail(ctx, SPH_E_STATE, "the one-launch rebuild gave up at a grid barrier: its workgroups were not all resident (is another "
@@ -1275,6 +1284,21 @@ int sph_slab_set_peer_links(sph_ctx *ctx, const sph_peer_links *links) {
     return SPH_OK;
 }
 
+// Test hook (tests/test_slab_c_host.py): $SPH_TEST_STALL_AFTER_HEAD = "rank:microseconds:every" holds that rank's HOST for so long
+// between the head kernel and the rest of every `every`-th step — what time-slicing does to ranks that share a device.  Its
+// neighbours run a launch ahead meanwhile (their next head kernel pushes its update and raises the arrival flag past the
+// value this rank is about to wait for: peer_wait).
+static void test_stall_after_head(int me, uint32_t step) {
+    static int rank = -2, us = 0, every = 1;
+    if (rank == -2) {
+        rank = -1;
+        const char *e = getenv("SPH_TEST_STALL_AFTER_HEAD");
+        if (e && sscanf(e, "%d:%d:%d", &rank, &us, &every) < 2) rank = -1;
+        if (every < 1) every = 1;
+    }
+    if (me == rank && us > 0 && step % (uint32_t)every == 0u) usleep((useconds_t)us);
+}
+
 int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
     if (!ctx->slab || ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_step: not a slab context, or mid-step");
@@ -1322,6 +1346,7 @@ int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
     }
     const float gravity[2] = {gx, gy};
     launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph, slab_verifies(ctx));                        // 1
+    if (peer) test_stall_after_head(L.me, step);
     launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 3 : 1, peer ? &pl : nullptr);   // 2
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, DENS_ALL, false);       // 3
     launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);                            // 4

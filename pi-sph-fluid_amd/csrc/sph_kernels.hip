@@ -1115,14 +1115,30 @@ __global__ __launch_bounds__(BLK) void k_force_direct(Consts c, const float2 *__
 // fence (the data has left this device's caches) and read with system-scope acquire loads in a kernel of its own (the
 // kernels that follow start with freshly invalidated caches).  All waits are bounded (FLAG_BAR_TIMEOUT -> SPH_E_STATE).
 constexpr uint32_t PEER_SPINS = 1u << 23;      // x ~0.2 us per poll: a few seconds
-DEV bool peer_wait(const uint32_t *__restrict__ word, const uint32_t tag, const uint32_t shift, uint32_t *__restrict__ flags, uint32_t &value) {
+DEV bool peer_wait(const uint32_t *__restrict__ word, const uint32_t tag, const uint32_t shift, uint32_t *__restrict__ flags, uint32_t &value,
+                   const uint32_t site = 0u) {
     uint32_t spins = 0u;
     for (;;) {
         value = __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // an arrival flag (shift 0) only grows — 2 x step for the update, 2 x step + 1 for the records — and the neighbour may be a
+        // launch AHEAD: the push blocks of its next head kernel do not wait for that launch's exchange block, so a rank whose launch was
+        // held up (ranks sharing a device are time-sliced) finds 2 x (step + 1) where it waits for 2 x step.  What it then reads is
+        // still there: receive buffers alternate with the step's parity, and the neighbour cannot begin step + 2 without this rank's
+        // word for step + 1 (k_slab_head).  The rebuild-word slots (shift 2) carry a payload under the step: equality, safe for the same reason.
+#ifdef SPH_PEER_WAIT_EQUAL      // (what rounds 3-5 shipped, for tools/lean_peer_probe.sh: the stalled rank gives up)
         if ((value >> shift) == tag) return true;
+#else
+        if (shift == 0u ? (int)(value - tag) >= 0 : (value >> shift) == tag) return true;
+#endif
         __builtin_amdgcn_s_sleep(4);
         if (++spins > PEER_SPINS) {
-            atomicOr(&flags[FLAG_BAR_TIMEOUT], 2u);      // (bit 1: a peer never arrived; bit 0 is the grid barrier's)
+            // (bit 1: a peer never arrived; bit 0 is the grid barrier's.)  The first to give up says where and over what
+            if ((atomicOr(&flags[FLAG_BAR_TIMEOUT], 2u) & 2u) == 0u) {
+                flags[FLAG_PEER_DIAG + 0] = site;
+                flags[FLAG_PEER_DIAG + 1] = tag << shift;
+                flags[FLAG_PEER_DIAG + 2] = value;
+                flags[FLAG_PEER_DIAG + 3] = flags[FLAG_STEP];
+            }
             return false;
         }
     }
@@ -1139,7 +1155,7 @@ __global__ __launch_bounds__(64) void k_peer_reduce(PeerSlots peers, const uint3
     if (q < nranks && q != me) {
         __hip_atomic_store(peers.of_rank[q] + par + (uint32_t)me, (tag << 2) | (w & 3u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         uint32_t v = 0u;
-        if (peer_wait(mine + par + (uint32_t)q, tag, 2u, flags, v)) got = v & 3u;
+        if (peer_wait(mine + par + (uint32_t)q, tag, 2u, flags, v, (1u << 8) | (uint32_t)q)) got = v & 3u;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) got = max(got, (uint32_t)__shfl_xor((int)got, d, 64));
@@ -1176,8 +1192,8 @@ __global__ __launch_bounds__(BLK) void k_peer_push(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(64) void k_peer_wait(const uint32_t *__restrict__ flag_l, const uint32_t *__restrict__ flag_r,
                                                   uint32_t *__restrict__ flags, uint32_t tag) {
     uint32_t v;
-    if (threadIdx.x == 0 && flag_l) (void)peer_wait(flag_l, tag, 0u, flags, v);
-    if (threadIdx.x == 1 && flag_r) (void)peer_wait(flag_r, tag, 0u, flags, v);
+    if (threadIdx.x == 0 && flag_l) (void)peer_wait(flag_l, tag, 0u, flags, v, 2u << 8);
+    if (threadIdx.x == 1 && flag_r) (void)peer_wait(flag_r, tag, 0u, flags, v, (2u << 8) | 1u);
 }
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag) {
     PeerSlots ps;
