@@ -211,6 +211,7 @@ bool speculative(const sph_ctx *ctx) { return !ctx->slab && fused(ctx) && ctx->r
 // verification made the collapse windows 5 % faster (fewer rebuilds) and every other window 10 - 15 % slower.  Every rank may choose
 // for itself: the rebuild word is MAX-reduced, all ranks rebuild in the same steps whoever verifies.
 bool slab_verifies(const sph_ctx *ctx) { return fused(ctx) && ctx->verify_mode > 0; }
+bool list_repair(const sph_ctx *ctx) { return !ctx->deterministic && (ctx->repair_mode < 0 ? ctx->n >= REPAIR_MIN_PARTICLES : ctx->repair_mode > 0); }
 void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
     hipStream_t st = ctx->stream;
     if (speculative(ctx) && !ev) {
@@ -218,7 +219,9 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
         // particles, cfg1: the verify jobs took the launch from 6 to 29 us to save rebuilds of 50 us in one step of a hundred)
         launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_ALL, false, true,
                        ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0);
-        launch_rebuild(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, true);
+        Arrays ga = ctx->a;
+        if (!list_repair(ctx)) ga.rq = nullptr;      // (no repairs, no queue of repaired tiles: the gate's workgroups do not look for one)
+        launch_rebuild(st, ctx->c, ga, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, true);
         launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);
         return;
     }
@@ -371,7 +374,7 @@ int upload_jobs(sph_ctx *ctx) {
     // collapse (steps 1200-2200, repairs in nearly every step) 8 660 -> 7 940, its other windows unchanged.
     // Slab contexts repair too (the verification blocks of their head kernel, k_slab_head): their density pass runs after the head
     // kernel, on the repaired lists — there is nothing to repeat and no queue.
-    const bool repair = !ctx->deterministic && (ctx->repair_mode < 0 ? ctx->n >= REPAIR_MIN_PARTICLES : ctx->repair_mode > 0);
+    const bool repair = list_repair(ctx);
     uint32_t *rq = repair && !ctx->slab ? a.rq : nullptr;
     const uint32_t repair_kind = !repair ? 0u : ctx->slab ? 2u : 1u;
     const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, first, a.pos_ref, vfirst, a.uref,
@@ -924,6 +927,7 @@ int sph_set_list_repair(sph_ctx *ctx, int mode) {
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->repair_mode = mode;
+    drop_graph(ctx);      // (an argument of the captured gate launch)
     return upload_jobs(ctx);
 }
 

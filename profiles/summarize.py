@@ -37,7 +37,58 @@ def pmc(path):
     return out
 
 
+def write_traffic(merged, path, workload):
+    """per-launch HBM traffic of the step kernels in bench.py's naming (read side doubled, see above) -> traffic.json[workload]"""
+    names = {"k_kick_drift<false>": "kick_drift", "k_key_hist<false>": "key_hist", "k_reorder": "reorder",
+             "k_build_list": "build_list", "k_density_list<1, 0>": "density_eos", "k_density_list<1, 0, true>": "density_eos",
+             "k_density_list<1, 0, false>": "density_eos_plain", "k_force_list<2, 0>": "force_kick", "k_check": "check",
+             "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply", "k_rebuild<0>": "rebuild"}
+    traffic, valu = {}, {}
+    for kn, bn in names.items():
+        cs = merged.get(kn, {})
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            traffic[bn] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
+        if "SQ_INSTS_VALU" in cs:      # wave-instructions per launch (all SIMDs); the transcendental ones issue at a quarter of the rate
+            valu[bn] = {"insts": int(cs["SQ_INSTS_VALU"]), "trans": int(cs.get("SQ_INSTS_VALU_TRANS", 0))}
+    if valu:
+        traffic["_valu"] = valu
+    if path and traffic:
+        import json
+        try:
+            allt = json.load(open(path))
+        except Exception:
+            allt = {}
+        allt[workload] = traffic
+        allt["_note"] = ("HBM-side bytes per launch from rocprofv3 PMC passes (profiles/collect.sh): 2 x FETCH_SIZE KiB + "
+                         "WRITE_SIZE KiB; the x2 is the gfx950 correction for wide coalesced reads "
+                         "(MI355X_MICROARCH.md, HBM) and is an upper bound where reads are 8 B/lane; "
+                         "Infinity-Cache hits are counted")
+        json.dump(allt, open(path, "w"), indent=1)
+
+
 def main():
+    if sys.argv[1] == "--trace-only":      # <dir> <out.md> <the profiled command, verbatim>: another program than bench.py (the C slab host)
+        d, out, cmd = sys.argv[2:5]
+        lines = ["# rocprofv3 summary: %s" % os.path.basename(d.rstrip("/")), "", "## per-kernel time (`rocprofv3 --kernel-trace --stats -- %s`)" % cmd, "",
+                 "| kernel | calls | avg us | % | min us | max us |", "|---|---|---|---|---|---|"]
+        for n, c, a, p, mn, mx in kernel_stats(os.path.join(d, "trace", "trace_kernel_stats.csv")):
+            lines.append("| %s | %d | %.2f | %.2f | %.2f | %.2f |" % (n, c, a, p, mn, mx))
+        open(out, "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
+        return
+    if sys.argv[1] == "--from-summary":    # <summary.md> <traffic.json> <workload>: the traffic entry again, from a committed summary's counter table
+        md, path, workload = sys.argv[2:5]
+        rows, hdr = {}, None
+        for ln in open(md):
+            cells = [c.strip() for c in ln.strip().strip("|").split("|")]
+            if ln.startswith("| kernel | ") and "SQ_INSTS_VALU" in ln:
+                hdr = cells
+            elif hdr and ln.startswith("| k_") and len(cells) == len(hdr):
+                rows[cells[0]] = {h: float(v) for h, v in zip(hdr[1:], cells[1:]) if v}
+            elif hdr and not ln.startswith("|"):
+                hdr = None
+        write_traffic(rows, path, workload)
+        return
     d = sys.argv[1]
     lines = ["# rocprofv3 summary: %s" % os.path.basename(d.rstrip("/")), ""]
     ks = os.path.join(d, "trace", "trace_kernel_stats.csv")
@@ -71,33 +122,8 @@ def main():
                 rd, wr = 2 * fs * 1024 / 1e6, ws * 1024 / 1e6
                 lines.append("| %s | %.0f | %.0f | %.2f | %.2f | %.2f |" % (kn, fs, ws, rd, wr, rd + wr))
         lines.append("")
-    # per-launch HBM traffic of the step kernels in bench.py's naming (read side doubled, see above)
-    names = {"k_kick_drift<false>": "kick_drift", "k_key_hist<false>": "key_hist", "k_reorder": "reorder",
-             "k_build_list": "build_list", "k_density_list<1, 0>": "density_eos", "k_density_list<1, 0, true>": "density_eos",
-             "k_density_list<1, 0, false>": "density_eos_plain", "k_force_list<2, 0>": "force_kick", "k_check": "check",
-             "k_scan_reduce": "scan_reduce", "k_scan_apply": "scan_apply", "k_rebuild<0>": "rebuild"}
-    traffic, valu = {}, {}
-    for kn, bn in names.items():
-        cs = merged.get(kn, {})
-        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            traffic[bn] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
-        if "SQ_INSTS_VALU" in cs:      # wave-instructions per launch (all SIMDs); the transcendental ones issue at a quarter of the rate
-            valu[bn] = {"insts": int(cs["SQ_INSTS_VALU"]), "trans": int(cs.get("SQ_INSTS_VALU_TRANS", 0))}
-    if valu:
-        traffic["_valu"] = valu
-    if len(sys.argv) > 3 and traffic:
-        import json
-        path, workload = sys.argv[3], (sys.argv[4] if len(sys.argv) > 4 else "cfg2")
-        try:
-            allt = json.load(open(path))
-        except Exception:
-            allt = {}
-        allt[workload] = traffic
-        allt["_note"] = ("HBM-side bytes per launch from rocprofv3 PMC passes (profiles/collect.sh): 2 x FETCH_SIZE KiB + "
-                         "WRITE_SIZE KiB; the x2 is the gfx950 correction for wide coalesced reads "
-                         "(MI355X_MICROARCH.md, HBM) and is an upper bound where reads are 8 B/lane; "
-                         "Infinity-Cache hits are counted")
-        json.dump(allt, open(path, "w"), indent=1)
+    if len(sys.argv) > 3:
+        write_traffic(merged, sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "cfg2")
     text = "\n".join(lines)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(text + "\n")
