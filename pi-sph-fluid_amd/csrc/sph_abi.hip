@@ -62,6 +62,7 @@ struct sph_ctx {
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
     hipGraph_t graph[8] = {};          // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations)
     hipGraphExec_t gexec[8] = {};
+    int slab_verify_most = 0;          // slab contexts: the most queued group pairs the head kernel verifies (more: the rebuild); 0 = the queue's capacity ($SPH_SLAB_VERIFY_MOST)
     int verify_mode = -1;              // failing box pairs verified particle by particle (spec_verify_job): -1 = from VERIFY_MIN_PARTICLES on, 0 = never (they ask for the rebuild), 1 = always (sph_set_verification)
     bool use_graph = true;
     int rebuild_wgs = 0;         // > 0: the rebuild chain of a step is ONE launch of this many workgroups (k_rebuild)
@@ -507,6 +508,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     if (make_consts(*prm, ctx->c) != SPH_OK) return fail(ctx, SPH_E_ARG, "invalid parameters (skin must be within [0, 1]) or grid too large");
     if (prm->deterministic != 0 && prm->deterministic != 1) return fail(ctx, SPH_E_ARG, "sph_params.deterministic must be 0 or 1");
     ctx->deterministic = prm->deterministic == 1;
+    if (getenv("SPH_SLAB_VERIFY_MOST")) ctx->slab_verify_most = atoi(getenv("SPH_SLAB_VERIFY_MOST"));
     if (getenv("SPH_NO_LIST_REPAIR")) ctx->repair_mode = 0;      // (A/B measurements: tools/ab_env5.sh)
     else if (getenv("SPH_LIST_REPAIR")) ctx->repair_mode = 1;
     ctx->skin = ctx->c.cell - 2 * prm->h;
@@ -1202,7 +1204,7 @@ int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
     // beyond skin/2 somewhere: compare the boxes, verify the failing ones particle by particle; may raise the rebuild word
     PeerHead none = {};
     none.nranks = 1;
-    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, none, slab_verifies(ctx));
+    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, none, slab_verifies(ctx), ctx->slab_verify_most);
     ctx->lean_step++;      // (the device counts the same steps: the tags of the lean step's messages, should the host switch to it)
     HIPCHK(ctx, hipGetLastError());
     ctx->slab_phase = 1;
@@ -1349,7 +1351,7 @@ int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
         }
     }
     const float gravity[2] = {gx, gy};
-    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph, slab_verifies(ctx));                        // 1
+    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph, slab_verifies(ctx), ctx->slab_verify_most);                     // 1
     if (peer) test_stall_after_head(L.me, step);
     launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 3 : 1, peer ? &pl : nullptr);   // 2
     launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, DENS_ALL, false);       // 3

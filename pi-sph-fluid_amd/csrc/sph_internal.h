@@ -269,7 +269,7 @@ struct PeerLinks {     // k_rebuild_slab, lean: wait for the update | exchange t
     const uint32_t *my_flag_l, *my_flag_r;           // this rank's own arrival flags (what its neighbours raise)
     uint32_t step;
 };
-void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph, bool verify);
+void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph, bool verify, int verify_most = 0);
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag);
 void launch_peer_push(hipStream_t st, const Consts &c, const Arrays &a, void *remote_l, void *flag_l, void *remote_r, void *flag_r, uint32_t tag);
 void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const void *flag_r, uint32_t tag);
