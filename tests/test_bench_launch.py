@@ -162,6 +162,26 @@ def test_one_gpu_references_are_keyed_by_window(tmp_path, monkeypatch):
     assert bench.cached_n1() == {}
 
 
+def test_the_faster_of_two_transports_that_agree_is_the_headline():
+    """--transport best (the default at N > 1): the RCCL run is the line's value unless the guarded peer run of the same window
+    completed, computed the same flow (every particle owned once, max rho and max speed equal to rounding) and is faster."""
+    sys.path.insert(0, ROOT)
+    import bench
+    rccl = {"particles_conserved": True, "n_fluid": 16000000, "n_gpus": 8, "steps": 20, "warmup": 5, "workload": "dam", "max_rho": 1003.21,
+            "max_speed": 0.0412, "ticks_per_s": 7000.0}
+    peer = dict(rccl, ticks_per_s=9100.0, max_rho=1003.2101, max_speed=0.04121)
+    assert bench.transports_agree(rccl, peer)
+    assert bench.choose_headline(rccl, {"status": "ok", "raw": peer})[0] == "peer"
+    assert bench.choose_headline(rccl, {"status": "ok", "raw": dict(peer, ticks_per_s=7050.0)})[0] == "rccl"       # not faster by the margin
+    assert bench.choose_headline(rccl, {"status": "timed out"})[0] == "rccl"
+    assert bench.choose_headline(rccl, None)[0] == "rccl"
+    for bad in (dict(peer, particles_conserved=False), dict(peer, max_rho=1010.0), dict(peer, max_speed=0.08), dict(peer, steps=40),
+                dict(peer, n_gpus=4), {k: v for k, v in peer.items() if k != "max_rho"}):
+        assert not bench.transports_agree(rccl, bad), bad
+        which, why = bench.choose_headline(rccl, {"status": "ok", "raw": bad})
+        assert which == "rccl" and "agree" in why
+
+
 @pytest.mark.gpu
 def test_six_ranks_rehearsal_weak_and_strong_legs(sph, tmp_path):
     """The N > 1 line as the driver's 8-GPU node will get it, rehearsed on the one GPU of this box: `bench.py --gpus 6` over
