@@ -1,9 +1,10 @@
-"""tools/dbg_slab_repair.py — slabs with / without verification and list repair against a single context, step by step (what
-tests/test_gpu_slab.py::test_slabs_repair_their_lists asserts).  (GPU box.)"""
+"""tests/dbg_slab_repair.py — slabs with / without verification and list repair against a single context, step by step (what
+tests/test_gpu_slab.py::test_slabs_repair_their_lists asserts).  Not collected by pytest (no test_ prefix): python tests/dbg_slab_repair.py on the GPU box."""
 import sys, os, importlib, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc      # (the checker's particle layout: this script lives under tests/ for that reason)
 from conftest import particles
 sph = importlib.import_module("pi-sph-fluid_amd")
 L = sph.hip_lib()
