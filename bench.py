@@ -472,6 +472,27 @@ def one_gpu_reference(sph, key, warmup, steps, windows, measure=True):
         return {"timesteps_per_s": None, "reference": "unavailable: %r" % (e_,), "window": [warmup, steps, windows]}
 
 
+def run_guarded(cmd, env, what):
+    """A run of the C host under a time limit ($SPH_BENCH_LEG_TIMEOUT seconds, default 600: the longest leg — cfg4 developed, 2 600
+    steps of 32 M particles over N ranks plus their creation — takes under a minute): a transport that never ran between GPUs may also
+    never return, and a bench that hangs reports nothing at all.  The child is a session of its own (the host's launcher and its
+    ranks): on a time-out the whole group is killed and the leg counts as failed (exit 124).  Returns (returncode, stdout bytes)."""
+    import signal
+    limit = float(os.environ.get("SPH_BENCH_LEG_TIMEOUT", "600"))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        so, _ = p.communicate(timeout=limit)
+        return p.returncode, so
+    except subprocess.TimeoutExpired:
+        log("bench.py: %s did not return within %.0f s: killed" % (what, limit))
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        so, _ = p.communicate()
+        return 124, so
+
+
 def c_host_cmd(host, scene, steps, warmup, transport, tilt, breakdown=30, windows=1):
     cmd = [host, "--scene", scene, "--steps", str(steps), "--warmup", str(warmup), "--windows", str(windows), "--transport", transport,
            "--breakdown", str(breakdown)]
@@ -494,9 +515,9 @@ def c_host_run(host, scene, steps, warmup, transport, tilt, world_env, tag, wind
         cmd += ["--ranks", str(world or 1)]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
-    return r.returncode, (json.loads(lines[-1]) if lines else None)
+    rc, so = run_guarded(cmd, env, "slab_sph_fluid (%s, %s)" % (transport, tag))
+    lines = [ln for ln in so.decode(errors="replace").splitlines() if ln.startswith("{")]
+    return rc, (json.loads(lines[-1]) if lines else None)
 
 
 def leg_summary(d, world, ref=None, weak=False):
@@ -704,9 +725,9 @@ def _own_ranks(host, scene, steps, warmup, transport, tilt, n_ranks, windows=1):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
-    return r.returncode, (json.loads(lines[-1]) if lines else None)
+    rc, so = run_guarded(cmd, env, "slab_sph_fluid --ranks %d (%s)" % (n_ranks, transport))
+    lines = [ln for ln in so.decode(errors="replace").splitlines() if ln.startswith("{")]
+    return rc, (json.loads(lines[-1]) if lines else None)
 
 
 def peer_leg(host, scene, world, steps, warmup, tilt, windows=1):

@@ -162,6 +162,20 @@ def test_one_gpu_references_are_keyed_by_window(tmp_path, monkeypatch):
     assert bench.cached_n1() == {}
 
 
+def test_a_leg_that_never_returns_is_killed_and_counts_as_failed(monkeypatch):
+    """the multi-rank legs of the bench run under a time limit (bench.run_guarded): a transport that has never run between GPUs may
+    also never return, and a bench that hangs reports nothing.  The whole process group goes (the launcher and its ranks)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("SPH_BENCH_LEG_TIMEOUT", "0.5")
+    t0 = time.time()
+    rc, so = bench.run_guarded(["bash", "-c", "echo started; sleep 30 & sleep 30"], dict(os.environ), "a leg that hangs")
+    assert rc == 124 and time.time() - t0 < 10 and b"started" in so
+    monkeypatch.setenv("SPH_BENCH_LEG_TIMEOUT", "30")
+    rc, so = bench.run_guarded(["bash", "-c", "echo '{\"ok\": 1}'; exit 3"], dict(os.environ), "a leg that fails")
+    assert rc == 3 and b'{"ok": 1}' in so
+
+
 def test_the_faster_of_two_transports_that_agree_is_the_headline():
     """--transport best (the default at N > 1): the RCCL run is the line's value unless the guarded peer run of the same window
     completed, computed the same flow (every particle owned once, max rho and max speed equal to rounding) and is faster."""
