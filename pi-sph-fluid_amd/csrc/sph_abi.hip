@@ -60,8 +60,8 @@ struct sph_ctx {
     bool acc_stale = false;      // ... nor the acceleration: refresh_acc() before use, and before anything it depends on changes
     bool stepped = false;        // a step has run since creation / upload / sph_eval_accel (sph_time_kernel needs it)
     float2 *pos_a = nullptr;     // the array a.pos pointed at when the context was created (graph index 0)
-    hipGraph_t graph[8] = {};          // [0,1]: one step; [2,3] / [4,5] / [6,7]: 2 / 4 / 8 steps (x the two orientations)
-    hipGraphExec_t gexec[8] = {};
+    hipGraph_t graph[16] = {};         // [0,1]: one step; [2 j, 2 j + 1]: 2^j steps, j = 1 .. 6 (x the two orientations)
+    hipGraphExec_t gexec[16] = {};
     int slab_verify_most = 0;          // slab contexts: the most queued group pairs the head kernel verifies (more: the rebuild); 0 = the queue's capacity ($SPH_SLAB_VERIFY_MOST)
     int verify_mode = -1;              // failing box pairs verified particle by particle (spec_verify_job): -1 = from VERIFY_MIN_PARTICLES on, 0 = never (they ask for the rebuild), 1 = always (sph_set_verification)
     bool use_graph = true;
@@ -246,7 +246,7 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
 }
 
 void drop_graph(sph_ctx *ctx) {
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 16; k++) {
         if (ctx->gexec[k]) { (void)hipGraphExecDestroy(ctx->gexec[k]); ctx->gexec[k] = nullptr; }
         if (ctx->graph[k]) { (void)hipGraphDestroy(ctx->graph[k]); ctx->graph[k] = nullptr; }
     }
@@ -278,10 +278,14 @@ hipGraphExec_t step_graph(sph_ctx *ctx) {
 // MULTI_STEPS consecutive steps of the fused (primed) loop as ONE graph: a replay has a fixed cost of several
 // microseconds whatever it holds, and sph_step(nsteps) usually asks for many steps.  An even number of steps leaves the
 // orientation of the two position / velocity sets as it was.
-constexpr int MULTI_STEPS = 8;      // the largest; 4 and 2 serve the remainder of a call (20 steps = 8 + 8 + 4: three replays)
+#ifndef SPH_MULTI_STEPS
+#define SPH_MULTI_STEPS 16
+#endif
+constexpr int MULTI_STEPS = SPH_MULTI_STEPS;      // the largest (a power of two, at most 64); the smaller powers serve the remainder of a call (20 steps = 16 + 4: two replays).  Round 5, same box: 8 -> 16: cfg1 48.0k -> 49.0k steps/s, cfg0 +1.3 %, cfg2 +0.3 %, the 20-step window unchanged; 32: no more
+static_assert(MULTI_STEPS >= 2 && MULTI_STEPS <= 64 && (MULTI_STEPS & (MULTI_STEPS - 1)) == 0, "MULTI_STEPS");
 hipGraphExec_t multi_graph(sph_ctx *ctx, int steps = MULTI_STEPS) {
-    if (!ctx->use_graph || (steps != 8 && steps != 4 && steps != 2)) return nullptr;
-    const int k = (steps == 8 ? 6 : steps == 4 ? 4 : 2) + (ctx->a.pos == ctx->pos_a ? 0 : 1);
+    if (!ctx->use_graph || steps < 2 || steps > MULTI_STEPS || (steps & (steps - 1)) != 0) return nullptr;
+    const int k = 2 * (31 - __builtin_clz((unsigned)steps)) + (ctx->a.pos == ctx->pos_a ? 0 : 1);
     if (ctx->gexec[k]) return ctx->gexec[k];
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
@@ -738,7 +742,8 @@ int sph_step(sph_ctx *ctx, float gx, float gy, int nsteps) {
     int s = 0;
     while (s < nsteps) {
         if (fused(ctx) && ctx->primed && nsteps - s >= 2) {
-            const int m = nsteps - s >= 8 ? 8 : nsteps - s >= 4 ? 4 : 2;
+            int m = MULTI_STEPS;
+            while (m > nsteps - s) m >>= 1;
             hipGraphExec_t g = multi_graph(ctx, m);
             if (g) {
                 HIPCHK(ctx, hipGraphLaunch(g, ctx->stream));
