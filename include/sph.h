@@ -72,7 +72,10 @@ typedef struct sph_params {
                             as long as both rebuild in the same steps (the order follows the cells at the last rebuild):
                             always with skin = 0; with a skin, a slab may rebuild a step earlier than a single context
                             would (waves next to ghost particles use the absolute criterion) */
-    float skin_min;      /* 0.12   the SMALLEST skin (ABI v6).  skin_min < skin: the skin adapts — every rebuild looks at how many
+    float skin_min;      /* 0.08   the SMALLEST skin (ABI v6; round 5: 0.08, was 0.12 — and reached only by lists that follow lists which
+                            lived 100 steps or longer: a fluid at rest or sloshing gently; lists that died sooner are followed by
+                            lists of at least 1.5 skin_min = the old 0.12; the first lists of a context have skin_min).
+                            skin_min < skin: the skin adapts — every rebuild looks at how many
                             steps the last lists lasted (how fast the flow uses up a skin) and picks the skin that minimises
                             list-walking cost + rebuild cost per step for that rate: larger in a violent flow (a rebuild costs
                             more than two steps), smaller in a calm one (shorter lists, cheaper steps).  skin_min >= skin (or

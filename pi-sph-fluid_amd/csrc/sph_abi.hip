@@ -593,6 +593,10 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     // one launch for the rebuild chain: single-GPU contexts by default; a slab context only when its host asks for it
     // (sph_set_rebuild_launches): several slabs may share a device, in one process or in several
     ctx->rebuild_wgs = slab ? 0 : rebuild_grid(ctx->device, ctx->cap);
+    if (const char *e = getenv("SPH_REBUILD_WGS_MOST")) {      // (measurements: tools/ab_env_small.sh)
+        const int most = atoi(e) - atoi(e) % 8;
+        if (most >= 8 && ctx->rebuild_wgs > most) ctx->rebuild_wgs = most;
+    }
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(a.count, 0, pad * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.dirty, 0, tiles * sizeof(uint32_t), st));

@@ -15,7 +15,7 @@ void sph_params_default(sph_params *p) {
     p->alpha = 0.01f; p->eps = 0.01f; p->k1 = 0.1f; p->k2 = 0.2f;   /* :325, :332, :334 */
     p->deterministic = 0;
     p->skin = 0.30f;                 /* neighbour-structure reuse: the skin adapts between skin_min and skin (fixed skins on the 2M-particle */
-    p->skin_min = 0.12f;             /* dam break: 0.15 is best while the fluid is at rest, 0.30 once the flow has developed) */
+    p->skin_min = 0.08f;             /* dam break: 0.15 is best while the fluid is at rest, 0.30 once the flow has developed); skin_min: where lists live long; 1.5 x that otherwise (adapt_skin) */
 }
 
 int sph_abi_version(void) { return SPH_ABI_VERSION; }

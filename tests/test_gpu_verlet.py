@@ -187,7 +187,7 @@ def test_verification_instead_of_rebuilds(sph, orc):
 
 def test_skin_controller(sph, orc):
     """the default skin adapts to how long the lists last (adapt_skin, csrc/sph_kernels.hip): particles that cross a
-    skin within a few steps drive it up to sph_params.skin, a tank at rest keeps it at skin_min (that the controller also
+    skin within a few steps drive it up to sph_params.skin, a tank at rest keeps it between skin_min and 1.5 skin_min (that the controller also
     comes back down shows in the long dam-break runs: tools/skin_sweep_gpu.py, tools/soak_gpu.py); the lists stay
     exact throughout (they are checked against the exact walk)."""
     rng = np.random.default_rng(11)
@@ -208,11 +208,13 @@ def test_skin_controller(sph, orc):
         assert abs(ctx.current_skin() - prm.skin) <= 1e-6, ctx.current_skin()
     prm, f, b = sph.scene_block((0.0, 30.6, 0.0, 8.0), 0.3, 0.3, 400, 60)      # a tank filled wall to wall: at rest
     with sph.Context(prm, f, b, GX, GY) as ctx:
-        ctx.step(650, GX, GY)      # (lists last > 150 steps here; later this tank starts to slosh)
+        ctx.step(650, GX, GY)      # (lists last ~100 steps and longer here; later this tank starts to slosh)
         ctx.sync()
         lists_vs_exact_walk(ctx, "tank")
         r, direct = ctx.rebuild_stats()
-        assert r >= 2 and abs(ctx.current_skin() - prm.skin_min) <= 1e-6, (ctx.current_skin(), r)      # asked, stayed
+        # asked, and stayed at the low end: skin_min itself after lists that lived 100 steps or longer, at most 1.5 skin_min (the floor
+        # behind lists that died sooner: adapt_skin) while the tank is this calm
+        assert 2 <= r <= 10 and prm.skin_min - 1e-6 <= ctx.current_skin() <= 1.5 * prm.skin_min + 1e-6, (ctx.current_skin(), r)
         assert direct == 0
 
 

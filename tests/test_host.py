@@ -134,7 +134,7 @@ def test_skin_is_a_per_context_parameter(sph):
     device cell 2H (1 + skin) of THEIR parameters (no process-wide state)."""
     L = sph.hip_lib()
     prm = sph.default_params()
-    assert abs(prm.skin - 0.30) < 1e-7 and abs(prm.skin_min - 0.12) < 1e-7      # the largest and smallest skin
+    assert abs(prm.skin - 0.30) < 1e-7 and abs(prm.skin_min - 0.08) < 1e-7      # the largest and smallest skin
     two_h = np.float32(2) * np.float32(prm.h)
     for frac in (0.0, 0.1, 0.4):
         prm.skin = frac
