@@ -174,7 +174,8 @@ int  sph_set_verification(sph_ctx *ctx, int mode);
  * of the lane's window bytes and the lane (or, by half a row, its wave) has room — instead of asking for the rebuild of everything;
  * the density of the repaired tiles is repeated in the same step.  Exact either way (tests/test_gpu_verlet.py: lists against the
  * walk over the cell ranges).  mode -1 = automatic: from 4 000 000 particles on (a rebuild of 32 M particles costs 4.2 ms, of 2 M
- * 0.28 ms; a step with repairs ~10 us), 0 = never, 1 = always.  Counters: sph_diag.h. */
+ * 0.28 ms; a step with repairs ~10 us), 0 = never, 1 = always.  Switching it on asks for one rebuild (lists built while it was off
+ * carry neither the spare row of padding nor the remembered partners a repair needs).  Counters: sph_diag.h. */
 int  sph_set_list_repair(sph_ctx *ctx, int mode);
 /* total particles clamped into the domain so far (0 in a healthy run) */
 long long sph_out_of_domain_count(sph_ctx *ctx);

@@ -221,7 +221,10 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
         launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_ALL, false, true,
                        ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0);
         Arrays ga = ctx->a;
-        if (!list_repair(ctx)) ga.rq = nullptr;      // (no repairs, no queue of repaired tiles: the gate's workgroups do not look for one)
+        if (!list_repair(ctx)) {      // no repairs: no queue of repaired tiles (the gate's workgroups do not look for one), and the list build
+            ga.rq = nullptr;          // writes neither the remembered partners (8 B per particle) nor the spare row of padding (4 B): at
+            ga.xpair = nullptr;       // 2 M particles 24 MB per rebuild that only a repair would read
+        }
         launch_rebuild(st, ctx->c, ga, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, true);
         launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);
         return;
@@ -937,8 +940,11 @@ int sph_set_list_repair(sph_ctx *ctx, int mode) {
     if (!ctx || !ctx->stream || mode < -1 || mode > 1) return SPH_E_ARG;
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const bool before = list_repair(ctx);
     ctx->repair_mode = mode;
     drop_graph(ctx);      // (an argument of the captured gate launch)
+    // lists built while repairs were off have neither the spare row nor the remembered partners: the next step rebuilds them
+    if (list_repair(ctx) && !before) launch_request_rebuild(ctx->stream, ctx->a);
     return upload_jobs(ctx);
 }
 

@@ -396,4 +396,5 @@ def test_slabs_repair_their_lists(sph, orc):
         rebuilds[repair] = slabs[0].rebuilds()
         for s_ in slabs:
             s_.close()
-    assert rebuilds[1] <= rebuilds[0], rebuilds
+    # (switching the repair on asks for ONE rebuild: lists built while it was off have neither the spare row nor the remembered partners)
+    assert rebuilds[1] <= rebuilds[0] + 1, rebuilds
