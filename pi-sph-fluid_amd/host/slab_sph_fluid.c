@@ -732,7 +732,7 @@ int main(int argc, char **argv) {
     int nranks = 1, rank = -1, steps = 200, warmup = 50, windows = 1, tilt = 0, check = 0, deterministic = 0, transport = TR_RCCL;
     int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2, breakdown = 0, halo_capacity = -1;
     int repair_opt = -1;                        /* --repair -1 (default: from 4 000 000 particles per slab on) | 0 | 1: sph_set_list_repair */
-    int verify_opt = -1;                        /* --verify -1 (default: from 500 000 particles per slab on) | 0 | 1: sph_set_verification */
+    int verify_opt = -1;                        /* --verify -1 (default: the library's — slab contexts verify only when asked: 1) | 0 | 1: sph_set_verification */
     int lean_opt = -1, one_launch_wgs = 0;      /* --lean auto (-1) | 0 | 1; --one-launch-wgs N: cap of the one-launch kernels' grid (ranks that share a device) */
     float skin = -1;
     const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL;
