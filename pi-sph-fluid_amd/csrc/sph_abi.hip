@@ -565,7 +565,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     const size_t nwaves = ntiles * (SPH_TILE_PARTICLES / BOXG);      // box groups
     ALLOC(a.wbox, nwaves); ALLOC(a.wnbr, (size_t)WNBR_WORDS * nwaves);
     a.vq = nullptr;
-    ALLOC(a.vq, 2 + 2 * (size_t)VQ_CAP);      // (slab contexts too: the verification blocks of their head kernel, k_slab_head)
+    ALLOC(a.vq, 2 + 2 * (size_t)vq_capacity(ctx->cap));      // (slab contexts too: the verification blocks of their head kernel, k_slab_head)
     a.rq = nullptr;
     if (!slab) { ALLOC(a.rq, RQ_CAP); }
     a.djobs[0] = a.djobs[1] = nullptr;
@@ -624,7 +624,12 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
         const float hdyn[DYN_COUNT] = {0.0f, 0.0f, 0.0f, c.skin_min, 0.0f, 0.0f};
         a.uref = ctx->slab ? nullptr : a.dyn + DYN_UREF_X;      // (slabs: the absolute criterion — their references would differ)
         HIPCHK(ctx, hipMemcpyAsync(a.dyn, hdyn, sizeof hdyn, hipMemcpyHostToDevice, st));
-        if (a.vq) HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (2 + 2 * (size_t)VQ_CAP), st));
+        if (a.vq) {
+            const uint32_t head[2] = {0u, (uint32_t)vq_capacity(ctx->cap)};
+            HIPCHK(ctx, hipMemsetAsync(a.vq, 0, sizeof(uint32_t) * (2 + 2 * (size_t)vq_capacity(ctx->cap)), st));
+            HIPCHK(ctx, hipMemcpyAsync(a.vq, head, sizeof head, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));      // (a local)
+        }
         if ((rc = upload_jobs(ctx)) != SPH_OK) return rc;
     }
 

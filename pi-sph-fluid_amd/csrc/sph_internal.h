@@ -223,7 +223,12 @@ constexpr float FAR_AWAY = 1.0e9f;       // coordinate of the dummy particle lis
 #ifndef SPH_VQ_CAP
 #define SPH_VQ_CAP 4096
 #endif
-constexpr int VQ_CAP = SPH_VQ_CAP;    // pairs of groups the verification queue holds (more: rebuild)
+constexpr int VQ_CAP = SPH_VQ_CAP;    // pairs of groups the verification queue holds (more: rebuild) ...
+// ... in contexts of up to VQ_LARGE_FROM particles; 8 x that beyond (round 5: cfg4's developed flow, 32 M particles, 608 -> 619 steps/s with
+// 32 768; at 2 M particles a larger queue LOSES — 16 384: -19 % in the first window: the verify jobs take on what they cannot finish
+// inside the launch).  The capacity lives in vq[1].
+constexpr int VQ_LARGE_FROM = 8000000;
+inline int vq_capacity(long long n) { return n >= VQ_LARGE_FROM ? 8 * VQ_CAP : VQ_CAP; }
 constexpr int RQ_CAP = 2048;          // tiles one step's list repairs may queue for a repeat of their density (more: rebuild)
 constexpr int HALO_HDR = 4;     // header words of a halo buffer (below)
 constexpr int HALO_REC = 5;     // words per halo record
