@@ -60,6 +60,36 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
+def box_calibration(sph):
+    """What THIS box delivers (sph_box_calibrate, include/sph_diag.h): 3 x ~50 ms of a streaming copy over 1 GiB and of a saturated
+    v_fma_f32 stream, medians.  The boxes of the pool differ by +-5-8 % for one build of the library; with this record a figure can be
+    normalised for its box (`*_vs_copy`: fractions of the MEASURED copy bandwidth instead of the 8 TB/s specification)."""
+    try:
+        b = sph.box_calibrate(0, 3)
+        b["what"] = ("copy_gbs: read + write bytes / time of a float4 copy kernel over 1 GiB; valu_cycles: SIMD-cycles per wave-instruction "
+                     "of an independent v_fma_f32 stream on every SIMD, priced at the nominal %.1f GHz (tools/ubench_valu); clock_ghz: "
+                     "s_memtime ticks per s_memrealtime tick x 100 MHz under that load; medians of %d runs of ~50 ms each, before the timed region" % (CLOCK_GHZ, b["repeats"]))
+        return b
+    except Exception as e_:      # (reported, never raised)
+        log("box calibration failed: %r" % (e_,))
+        return {"status": "failed: %r" % (e_,)}
+
+
+def vs_copy(rf, box):
+    """the roofline's fractions once more against the copy bandwidth measured on this box"""
+    c = (box or {}).get("copy_gbs")
+    if not c or not rf:
+        return rf
+    rf = dict(rf)
+    if rf.get("achieved"):
+        rf["frac_vs_copy"] = round(rf["achieved"] / c, 4)
+    if rf.get("step_achieved"):
+        rf["step_frac_vs_copy"] = round(rf["step_achieved"] / c, 4)
+    if rf.get("step_frac_executed") is not None:
+        rf["step_frac_executed_vs_copy"] = round(rf["step_frac_executed"] * HBM_PEAK_GBS / c, 4)
+    return rf
+
+
 # launches per kernel of the duration measurement in front of the timed region (run_single): enough of them that a fresh
 # box has reached its running clocks when the window starts — the driver times 20 steps (2 ms) after 5, and a GPU that
 # has worked for 5 ms in its life runs the force pass in 64 us instead of 53
@@ -586,8 +616,11 @@ def run_c_host(sph, args):
     the N ranks, once at rest (steps 50-650) and once developed (steps 2000-2600), each with its speed-up against the one-GPU rate
     on the SAME window (STRONG_LEGS; cached by this host's N = 1 run, else measured by rank 0 after the multi-rank legs) — and
     all of it once more over the peer transport (guarded: own process group, time limit).
-    --transport best (default): the RCCL run is the line's value unless the guarded peer run of the same window agrees with it and is
-    faster (choose_headline): then that one is, and the line says so.
+    Default (round 6): the RCCL run is the line's value; the guarded peer run of the same windows is reported beside it
+    (`peer_transport`) and never becomes the value.
+    --transport best (opt-in): the RCCL run is the line's value unless the guarded peer run of the same window agrees with it and is
+    faster (choose_headline): then that one is, and the line says so (`transport_used`, `value_is_max_of_two_runs`: a maximum of two
+    runs is biased upwards).
     --transport host: the same step loop with POSIX shared memory between the ranks (they may share a device: a rehearsal of
     the N-rank code path on fewer GPUs, not a measurement of xGMI).  --transport auto: rccl, and if that run fails the peer
     run becomes the line's value (said so in `transport_used`); without it a failing transport fails the bench."""
@@ -699,6 +732,7 @@ def run_c_host(sph, args):
         out["transport_used"] = "peer (--transport auto: the RCCL run of this bench did not complete: exit %d)" % rc
     if chosen:
         out["transport_choice"] = chosen      # --transport best: which of the two weak-leg runs is the line's value, and why
+        out["value_is_max_of_two_runs"] = True      # (a maximum of two runs is biased upwards: opt-in only, and said)
         out["scaling_detail"]["strong_transport"] = "rccl"      # (the strong legs under scaling_detail are the RCCL runs; the peer ones: peer_transport.strong)
         if rccl_weak_raw is not None:
             out["transport_used"] = "peer (--transport best: %s)" % chosen["why"]
@@ -828,13 +862,14 @@ def main():
     ap.add_argument("--save-state", default=None, help="N = 1: write the state after the warm-up (particles + accelerations, .npz)")
     ap.add_argument("--load-state", default=None, help="N = 1: start from a state written by --save-state (then --warmup, then the timed steps)")
     ap.add_argument("--tilt", action="store_true", help="N = 1: gravity from the scripted tilt trace (cfg4 is defined with it)")
-    ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "best"), choices=["best", "rccl", "host", "peer", "auto"],
+    ap.add_argument("--transport", default=os.environ.get("SPH_SLAB_TRANSPORT", "rccl"), choices=["best", "rccl", "host", "peer", "auto"],
                     help="N > 1: halo transport. rccl = RCCL over xGMI, one GPU per rank; host = host-staged (C host: POSIX "
                          "shared memory; python host: gloo): a rehearsal, all ranks may share one device; peer = stores into "
                          "hipIpc-mapped peer memory + flag words (C host), no collective library on the step path; auto = rccl, and "
-                         "should that run fail, peer (reported as such) — without it a failing transport fails the bench; best (default) = rccl, and "
+                         "should that run fail, peer (reported as such) — without it a failing transport fails the bench; rccl is the default "
+                         "(round 6: the line's value is the RCCL run, the guarded peer run is reported beside it under peer_transport); best (opt-in) = rccl, and "
                          "where the guarded peer run of the same window completes, agrees with the RCCL run (particles, max rho, max "
-                         "speed) and is faster, ITS figure is the line's value (both are reported; `transport_used` says so)")
+                         "speed) and is faster, ITS figure is the line's value (both are reported; `transport_used` and `value_is_max_of_two_runs` say so)")
     ap.add_argument("--lib", default=None, help="A/B measurements: load this build of libsph_hip.so instead of the in-tree one")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin as a fraction of 2H (default: the library's)")
     ap.add_argument("--slab-host", default="c", choices=["c", "python"],
@@ -866,6 +901,8 @@ def main():
         run_slabs(sph, args, emit)
         return
 
+    box = box_calibration(sph)      # before the timed region (it also brings a fresh box to its running clocks)
+    log("box:", json.dumps(box))
     res = run_single(sph, args.workload, args.steps, args.warmup, skin=args.skin, tilt=args.tilt, load_state=args.load_state,
                      save_state=args.save_state)
     log("primary:", json.dumps(res))
@@ -900,8 +937,9 @@ def main():
         "list_repairs": res["list_repairs"],
         # (the PMC traffic of the regime the window is in: steps 4000+ = the developed flow; the first ~100 steps = the fluid at
         # rest with the smallest skin — the driver's `--steps 20 --warmup 5`; otherwise the early collapse of steps 100-400)
-        "roofline": roofline(sph, res, None if args.workload != "cfg2" else "cfg2_developed" if args.warmup >= 3000 else
-                             "cfg2_at_rest" if args.warmup + args.steps <= 100 else None),
+        "roofline": vs_copy(roofline(sph, res, None if args.workload != "cfg2" else "cfg2_developed" if args.warmup >= 3000 else
+                                     "cfg2_at_rest" if args.warmup + args.steps <= 100 else None), box),
+        "box": box,
     }
 
     def also_entry(label, r, traffic_key, cache_key=None):
@@ -944,6 +982,9 @@ def main():
                             "value": e["value"], "unit": e["unit"], "timesteps_per_s": e["timesteps_per_s"],
                             "window_timesteps_per_s": e["window_timesteps_per_s"], "window_rebuilds_per_step": e["window_rebuilds_per_step"],
                             "step_frac": e["step_frac"], "step_frac_executed": e["step_frac_executed"]}
+        if box.get("copy_gbs"):      # ... and against what a streaming copy reaches on THIS box
+            out["sustained"]["step_frac_vs_copy"] = round(e["step_frac"] * HBM_PEAK_GBS / box["copy_gbs"], 4)
+            out["sustained"]["timesteps_per_s_per_copy_tbs"] = round(e["timesteps_per_s"] / (box["copy_gbs"] / 1e3), 1)
         r = run_single(sph, "cfg1", 1000, 200, skin=args.skin, windows=5)
         log("also:", json.dumps(r))
         out["also"].append(also_entry("cfg1: %d fluid + %d boundary, drop on dry surface, box 409.6 x 204.8 m" % (r["n_fluid"], r["n_boundary"]), r, "cfg1"))

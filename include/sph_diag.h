@@ -79,6 +79,22 @@ int   sph_repair_stats(sph_ctx *ctx, long long out[4]);
 /* steps so far in which somebody was beyond skin/2 and the relative-motion check had to run */
 int   sph_check_stats(sph_ctx *ctx, long long *checks);
 
+/* ---- box calibration (round 6) ----
+ * The boxes of a GPU pool differ (+-5-8 % in steps/s for one build of this library): a figure from one box cannot be held against a
+ * figure from another without knowing what the box itself delivers.  Two micro-measurements on `device`, ~50 ms each, nothing to do
+ * with any context:
+ *   copy_gbs     a streaming copy kernel over 1 GiB (read + write bytes / time): the memory system as a simple kernel finds it
+ *   valu_cycles  SIMD-cycles per wave-instruction of an independent v_fma_f32 stream with every SIMD saturated, priced at the
+ *                NOMINAL 2.4 GHz (tools/ubench_valu's figure: 2.67 there; it moves with the clock the box really runs)
+ *   clock_ghz    the shader clock under that load: ticks of the wave's cycle counter (s_memtime) over the 100 MHz constant
+ *                counter (s_memrealtime) across the kernel; 0 if the two counters turn out to be the same clock
+ * bench.py puts them into its JSON line (`box`) next to fractions taken against the MEASURED copy bandwidth. */
+typedef struct sph_box_calibration {
+    float copy_gbs, valu_cycles, clock_ghz;
+    float copy_ms, valu_ms;      /* duration of the two measurements */
+} sph_box_calibration;
+int   sph_box_calibrate(int device, sph_box_calibration *out);
+
 #ifdef __cplusplus
 }
 #endif

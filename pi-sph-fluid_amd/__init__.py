@@ -51,6 +51,7 @@ ABI_SYMBOLS = [      # include/sph.h: the drop-in boundary (+ slabs, metaballs)
 DIAG_SYMBOLS = [     # include/sph_diag.h: measurement and diagnostics (bench.py, profiling, tests)
     "sph_profile_steps", "sph_time_kernel", "sph_set_variant",
     "sph_direct_tile_reasons", "sph_verify_stats", "sph_rebuild_reasons", "sph_check_stats", "sph_repair_stats",
+    "sph_box_calibrate",
 ]
 HOST_SYMBOLS = [
     "sph_params_default", "sph_scene_default_fluid", "sph_scene_walls", "sph_scene_disc", "sph_scene_block",
@@ -71,6 +72,11 @@ class Params(C.Structure):
 
 class KernelTimes(C.Structure):
     _fields_ = [("ms", C.c_float * 8), ("step_ms", C.c_float), ("nsteps", C.c_int), ("rebuilds", C.c_int)]
+
+
+class BoxCalibration(C.Structure):
+    """sph_box_calibration of include/sph_diag.h."""
+    _fields_ = [("copy_gbs", C.c_float), ("valu_cycles", C.c_float), ("clock_ghz", C.c_float), ("copy_ms", C.c_float), ("valu_ms", C.c_float)]
 
 
 class SlabDesc(C.Structure):
@@ -351,6 +357,23 @@ class WallMotion:
         vx, vy = C.c_float(), C.c_float()
         host_lib().sph_wall_motion_update(C.byref(self.s), gx, gy, dt, C.byref(vx), C.byref(vy))
         return vx.value, vy.value
+
+
+def box_calibrate(device=0, repeats=3):
+    """sph_box_calibrate (include/sph_diag.h), `repeats` times: the median of each figure — what THIS box delivers to a streaming copy
+    and to a saturated v_fma_f32 stream, so that a steps/s figure can be told from the box it was measured on."""
+    L = hip_lib()
+    L.sph_box_calibrate.argtypes = [C.c_int, C.POINTER(BoxCalibration)]
+    rows = []
+    for _ in range(repeats):
+        b = BoxCalibration()
+        rc = L.sph_box_calibrate(device, C.byref(b))
+        if rc:
+            raise SphError(rc, "sph_box_calibrate failed")
+        rows.append((b.copy_gbs, b.valu_cycles, b.clock_ghz))
+    med = [float(np.median([r[k] for r in rows])) for k in range(3)]
+    return {"copy_gbs": round(med[0], 1), "valu_cycles": round(med[1], 3), "clock_ghz": round(med[2], 3) if med[2] > 0 else None,
+            "repeats": repeats, "copy_gbs_runs": [round(r[0], 1) for r in rows], "valu_cycles_runs": [round(r[1], 3) for r in rows]}
 
 
 class Context:

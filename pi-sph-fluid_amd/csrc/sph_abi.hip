@@ -397,9 +397,16 @@ int upload_jobs(sph_ctx *ctx) {
 }
 
 int check_flags(sph_ctx *ctx) {
-    uint32_t h[FLAG_COUNT] = {0};
+    uint32_t h[FLAG_HEAD_GAVE_UP + 1] = {0};
+    static_assert(FLAG_HEAD_GAVE_UP + 1 >= FLAG_COUNT && FLAG_HEAD_GAVE_UP < FLAG_WORDS, "one read-back for every word checked here");
     HIPCHK(ctx, hipMemcpyAsync(h, ctx->a.flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[FLAG_HEAD_GAVE_UP]) {      // (not a grid barrier of the rebuild: rebuild_wgs and the graphs stay as they are)
+        HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_HEAD_GAVE_UP, 0, sizeof(uint32_t), ctx->stream));
+        return fail(ctx, SPH_E_STATE, "slab step: the exchange block of the head kernel gave up waiting for the rebuild criterion's blocks of its own "
+                                      "launch (were they not all resident: is another process computing on this device?); those steps went out as "
+                                      "'rebuild' and are exact - the state is valid, the step is slower than it should be");
+    }
     if (h[FLAG_BAR_TIMEOUT]) {
         HIPCHK(ctx, hipMemsetAsync(ctx->a.flags + FLAG_BAR_TIMEOUT, 0, sizeof(uint32_t), ctx->stream));
         if (h[FLAG_BAR_TIMEOUT] & 2u) {      // (the peer transport's waits have a bit of their own: nothing is wrong with this rank's launches)
@@ -1203,6 +1210,95 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     return SPH_OK;
 }
 
+// ---- box calibration (sph_diag.h) ----
+namespace {
+__global__ __launch_bounds__(256) void k_cal_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+constexpr int CAL_ITERS = 4096, CAL_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void k_cal_valu(float *out, float seed, unsigned long long *clocks) {
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = seed + i + threadIdx.x * 1e-3f;
+    const float c1 = seed * 0.999f, c2 = seed * 1e-3f;
+    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long t0 = 0, w0 = 0;
+    if (stamp) { t0 = clock64(); w0 = wall_clock64(); }
+    for (int it = 0; it < CAL_ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = fmaf(a[i], c1, c2);
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (stamp) { clocks[0] = clock64() - t0; clocks[1] = wall_clock64() - w0; }
+}
+}  // namespace
+
+int sph_box_calibrate(int device, sph_box_calibration *out) {
+    if (!out) return SPH_E_ARG;
+    memset(out, 0, sizeof *out);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { (void)hipGetLastError(); return SPH_E_HIP; }
+    if (hipSetDevice(device) != hipSuccess) return SPH_E_HIP;
+    const size_t bytes = (size_t)1 << 30, n4 = bytes / sizeof(float4);
+    float4 *src = nullptr, *dst = nullptr;
+    float *vout = nullptr;
+    unsigned long long *clk = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    int rc = SPH_E_HIP;
+    do {
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&dst, bytes) != hipSuccess) { rc = SPH_E_NOMEM; break; }
+        if (hipMalloc(&vout, (size_t)CAL_BLOCKS * 256 * sizeof(float)) != hipSuccess || hipMalloc(&clk, 2 * sizeof(unsigned long long)) != hipSuccess) { rc = SPH_E_NOMEM; break; }
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        if (hipMemsetAsync(src, 0x3c, bytes, st) != hipSuccess || hipMemsetAsync(dst, 0, bytes, st) != hipSuccess) break;
+        // copy: two untimed passes, then as many as fill ~50 ms
+        const int grid = 256 * 16;
+        for (int k = 0; k < 2; k++) hipLaunchKernelGGL(k_cal_copy, dim3(grid), dim3(256), 0, st, src, dst, n4);
+        const int reps = 96;      // 96 x 2 GiB at ~4-5 TB/s ~ 45 ms
+        (void)hipEventRecord(e0, st);
+        for (int k = 0; k < reps; k++) hipLaunchKernelGGL(k_cal_copy, dim3(grid), dim3(256), 0, st, src, dst, n4);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        out->copy_ms = ms;
+        out->copy_gbs = ms > 0 ? (float)(2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9) : 0.0f;
+        // VALU issue: one untimed launch, then ~50 ms of launches (one launch: 2048 x 4 waves x 32768 v_fma ~ 0.3 ms)
+        hipLaunchKernelGGL(k_cal_valu, dim3(CAL_BLOCKS), dim3(256), 0, st, vout, 1.0001f, clk);
+        const int vreps = 160;
+        (void)hipEventRecord(e0, st);
+        for (int k = 0; k < vreps; k++) hipLaunchKernelGGL(k_cal_valu, dim3(CAL_BLOCKS), dim3(256), 0, st, vout, 1.0001f, clk);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        out->valu_ms = ms;
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        const double instr = (double)CAL_BLOCKS * 4.0 * CAL_ITERS * 8.0 * vreps;
+        out->valu_cycles = (float)(ms * 1e-3 * 2.4e9 * (4.0 * cus) / instr);
+        unsigned long long h[2] = {0, 0};
+        if (hipMemcpyAsync(h, clk, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) break;
+        // (s_memrealtime counts at 100 MHz; a ratio of ~1 means both counters are that clock on this stack: no figure)
+        const double ratio = h[1] ? (double)h[0] / (double)h[1] : 0.0;
+        out->clock_ghz = ratio > 1.5 ? (float)(ratio * 0.1) : 0.0f;
+        rc = hipGetLastError() == hipSuccess ? SPH_OK : SPH_E_HIP;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (vout) (void)hipFree(vout);
+    if (clk) (void)hipFree(clk);
+    if (st) (void)hipStreamDestroy(st);
+    if (rc != SPH_OK) (void)hipGetLastError();
+    return rc;
+}
+
 // ---- slab decomposition ----
 int sph_slab_step_begin(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
@@ -1310,10 +1406,11 @@ int sph_slab_set_peer_links(sph_ctx *ctx, const sph_peer_links *links) {
     return SPH_OK;
 }
 
-// Test hook (tests/test_slab_c_host.py): $SPH_TEST_STALL_AFTER_HEAD = "rank:microseconds:every" holds that rank's HOST for so long
+// Test hook, compiled with -DSPH_TEST_HOOKS only (tests/test_slab_c_host.py): $SPH_TEST_STALL_AFTER_HEAD = "rank:microseconds:every" holds that rank's HOST for so long
 // between the head kernel and the rest of every `every`-th step — what time-slicing does to ranks that share a device.  Its
 // neighbours run a launch ahead meanwhile (their next head kernel pushes its update and raises the arrival flag past the
 // value this rank is about to wait for: peer_wait).
+#ifdef SPH_TEST_HOOKS      // (`make stress`: libsph_hip_co.so + host/slab_sph_fluid_stress; the product build has no such hook)
 static void test_stall_after_head(int me, uint32_t step) {
     static int rank = -2, us = 0, every = 1;
     if (rank == -2) {
@@ -1324,6 +1421,9 @@ static void test_stall_after_head(int me, uint32_t step) {
     }
     if (me == rank && us > 0 && step % (uint32_t)every == 0u) usleep((useconds_t)us);
 }
+#else
+static inline void test_stall_after_head(int, uint32_t) {}
+#endif
 
 int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;

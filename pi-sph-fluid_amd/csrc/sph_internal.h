@@ -180,6 +180,8 @@ enum {
     FLAG_REPAIRS = 34,      // pairs appended to the lists so far instead of a rebuild (list_add: two entries each)
     FLAG_REPAIR_FAIL = 35,  // + k: repairs that were not possible and asked for the rebuild after all: (0) the partner is not staged within
                             //   reach of the lane's window bytes, (1) no free byte in the lane's rows, (2) the queue of repaired tiles is full
+    FLAG_HEAD_GAVE_UP = 38, // k_slab_head: its exchange block gave up waiting for the criterion's blocks of its own launch (count); that step
+                            //   went out as "rebuild": exact, reported by check_flags with a message of its own
     FLAG_PEER_DIAG = 40,    // + 0..3: the first peer wait that gave up: site (1 k_peer_reduce, 2 k_peer_wait, 3 head: rebuild word, 4 lean: update, 5 lean: records)
                             //   << 8 | side or rank, the tag it waited for, the word it saw last, this rank's step count
     FLAG_WORDS = 64

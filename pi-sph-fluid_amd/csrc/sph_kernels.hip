@@ -954,12 +954,22 @@ void launch_reorder(hipStream_t st, const Consts &c, const Arrays &a, int cap, b
 // Tait EOS, clamped at zero (:294-301): p = max(0, B((rho/rho0)^7 - 1)); also p/rho^2 for the force pass.
 // (rho / rho0 as a multiplication by 1 / rho0 and p / rho^2 through v_rcp_f32 — one ulp each, 1e-7 of gates that are 1e-5 wide —
 // instead of two IEEE divisions: ~25 of the density pass's ~450 vector instructions per wave)
+// -DSPH_EOS_IEEE (`make variant`: the bisect of tools/rho_gate_chaos.py's statistic on the GPU): the two IEEE divisions back.
+#ifdef SPH_EOS_IEEE
+DEV float eos_p_over_rho2(float p, float rho) { return p / (rho * rho); }
+#else
+DEV float eos_p_over_rho2(float p, float rho) { return p * __builtin_amdgcn_rcpf(rho * rho); }
+#endif
 DEV void eos(const Consts &c, float rho, float &p, float &p_over_rho2) {
+#ifdef SPH_EOS_IEEE
+    float r = rho / c.rho0;
+#else
     float r = rho * c.inv_rho0;
+#endif
     float r2 = r * r, r4 = r2 * r2;
     float r7 = r4 * r2 * r;
     p = fmaxf(c.B * (r7 - 1.0f), 0.0f);
-    p_over_rho2 = p * __builtin_amdgcn_rcpf(rho * rho);
+    p_over_rho2 = eos_p_over_rho2(p, rho);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1026,7 +1036,7 @@ __global__ __launch_bounds__(BLK) void k_eos(Consts c, float2 *__restrict__ rp, 
     if (i >= (int)dn[0]) return;
     float rho = rp[i].x;
     if (FROM_PRS) {
-        rp[i].y = prs[i] * __builtin_amdgcn_rcpf(rho * rho);      // (as eos())
+        rp[i].y = eos_p_over_rho2(prs[i], rho);      // (as eos())
     } else {
         float p, pr2;
         eos(c, rho, p, pr2);
@@ -1463,7 +1473,7 @@ __global__ __launch_bounds__(BLK) void k_gather_rho_p(const sph_particle *__rest
     int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
     sph_particle q = in[id[i]];
-    rp[i] = make_float2(q.rho, q.p * __builtin_amdgcn_rcpf(q.rho * q.rho));      // (as eos())
+    rp[i] = make_float2(q.rho, eos_p_over_rho2(q.p, q.rho));      // (as eos())
     prs[i] = q.p;
 }
 

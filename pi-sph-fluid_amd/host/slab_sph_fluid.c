@@ -998,7 +998,9 @@ int main(int argc, char **argv) {
             for (; k > 0 && sorted[k - 1] > win_rate[w]; k--) sorted[k] = sorted[k - 1];
             sorted[k] = win_rate[w];
         }
-        if (steps > 0 && sorted[n_win / 2] > 0) elapsed = (double)steps / sorted[n_win / 2];
+        /* (an even number of windows: the mean of the two middle ones, not the upper of them) */
+        const double med = n_win % 2 ? sorted[n_win / 2] : 0.5 * (sorted[n_win / 2 - 1] + sorted[n_win / 2]);
+        if (steps > 0 && med > 0) elapsed = (double)steps / med;
     }
     int rc = sph_sync(rs.ctx);                                                   /* capacity / out-of-domain / NaN */
     if (rc) { fprintf(stderr, "[rank %d] sph_sync: %d (%s)\n", rank, rc, sph_last_error(rs.ctx)); return 1; }

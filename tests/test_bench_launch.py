@@ -177,7 +177,7 @@ def test_a_leg_that_never_returns_is_killed_and_counts_as_failed(monkeypatch):
 
 
 def test_the_faster_of_two_transports_that_agree_is_the_headline():
-    """--transport best (the default at N > 1): the RCCL run is the line's value unless the guarded peer run of the same window
+    """--transport best (opt-in; the default is the RCCL run, the peer run beside it): the RCCL run is the line's value unless the guarded peer run of the same window
     completed, computed the same flow (every particle owned once, max rho and max speed equal to rounding) and is faster."""
     sys.path.insert(0, ROOT)
     import bench

@@ -19,6 +19,7 @@ import pytest
 from conftest import ROOT
 
 HOST = os.path.join(ROOT, "pi-sph-fluid_amd", "host", "slab_sph_fluid")
+HOST_STRESS = HOST + "_stress"      # `make stress`: the same host linked against the test build of the library (-DSPH_TEST_HOOKS)
 
 
 def test_c_partitioner_equals_python(sph):
@@ -144,8 +145,8 @@ def test_c_partition_counts_equals_python(sph):
     assert L.sph_slab_partition_counts(hist.ctypes.data_as(C.POINTER(C.c_longlong)), 10, 4, cuts) == sph.SPH_E_ARG
 
 
-def _run_host(args, timeout=600, env=None):
-    r = subprocess.run([HOST] + [str(a) for a in args], capture_output=True, timeout=timeout, env=None if env is None else dict(os.environ, **env))
+def _run_host(args, timeout=600, env=None, host=HOST):
+    r = subprocess.run([host] + [str(a) for a in args], capture_output=True, timeout=timeout, env=None if env is None else dict(os.environ, **env))
     out = r.stdout.decode().splitlines()
     rec = [json.loads(ln) for ln in out if ln.startswith("{")]
     return r, out, (rec[0] if rec else None)
@@ -249,13 +250,17 @@ def test_c_host_lean_step_with_a_rank_held_up_between_its_launches(sph, tmp_path
     launch's exchange block — and the arrival flag reads 2 (t + 1) where the rank that was held up waits for 2 t.  (Round 5: the
     wait was for equality; the four-rank bitwise test above gave up in one run of many with 'a neighbouring rank's ... did not
     arrive'.)  $SPH_TEST_STALL_AFTER_HEAD holds rank 1's host for 300 us between the head kernel and the rest of every third step:
-    the run ends cleanly and with the bits of the run nobody held up — the message of step t is still in the buffer of its parity."""
+    the run ends cleanly and with the bits of the run nobody held up — the message of step t is still in the buffer of its parity.
+    (Round 6: the hook is compiled into the TEST build of the library only — `make stress`, -DSPH_TEST_HOOKS — and both runs go through
+    host/slab_sph_fluid_stress, the C host linked against it; sph_slab_step one call per step: --lean-graph 0.)"""
+    if not os.path.exists(HOST_STRESS):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "pi-sph-fluid_amd"), "stress"])
     states = []
     for stall in (None, "1:300:3"):
         state = tmp_path / ("state_%s.bin" % (stall is not None))
         r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
-                                 "--velocity", 5, 0, "--steps", 200, "--warmup", 40, "--deterministic", "--dump-state", state],
-                                env=None if stall is None else {"SPH_TEST_STALL_AFTER_HEAD": stall})
+                                 "--velocity", 5, 0, "--steps", 200, "--warmup", 40, "--deterministic", "--lean-graph", 0, "--dump-state", state],
+                                env=None if stall is None else {"SPH_TEST_STALL_AFTER_HEAD": stall}, host=HOST_STRESS)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200 and "lean step" in rec["host"]
         states.append((np.fromfile(state, sph.PARTICLE), rec["neighbour_rebuilds"], rec["ticks_per_s"]))

@@ -1,12 +1,21 @@
-"""tests/dbg_slab_repair.py — slabs with / without verification and list repair against a single context, step by step (what
-tests/test_gpu_slab.py::test_slabs_repair_their_lists asserts).  Not collected by pytest (no test_ prefix): python tests/dbg_slab_repair.py on the GPU box."""
+"""tools/dbg_slab_repair.py — slabs with / without verification and list repair against a single context, step by step (what
+tests/test_gpu_slab.py::test_slabs_repair_their_lists asserts).  A debugging aid: python tools/dbg_slab_repair.py on the GPU box."""
 import sys, os, importlib, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import orc      # (the checker's particle layout: this script lives under tests/ for that reason)
-from conftest import particles
+sys.path.insert(0, ROOT)
 sph = importlib.import_module("pi-sph-fluid_amd")
+
+
+def particles(state, m, rho0=1000.0):
+    f = np.zeros(len(state), sph.PARTICLE)
+    f["x"], f["y"], f["u"], f["v"] = state[:, 0], state[:, 1], state[:, 2], state[:, 3]
+    f["m"] = m
+    f["rho"] = rho0
+    return f
+
+
+
 L = sph.hip_lib()
 rng = np.random.default_rng(11)
 box = (0.0, 16.0, 0.0, 16.0)
@@ -17,7 +26,7 @@ xy = np.array([1.7, 6.5]) + 0.075 * np.stack([gx.ravel(), gy.ravel()], 1) + rng.
 inner = ((gx.ravel() >= 24) & (gx.ravel() < 60)) | ((gx.ravel() >= 108) & (gx.ravel() < 144))
 uv = rng.uniform(-40.0, 40.0, (nx * ny, 2)) * ((rng.random(nx * ny) < 0.2) & inner)[:, None]
 state = np.concatenate([xy, uv], 1).astype(np.float32)
-f = particles(orc, state, np.float32(prm.rho0) * np.float32(prm.vol))
+f = particles(state, np.float32(prm.rho0) * np.float32(prm.vol))
 _p, _f, walls = sph.scene_disc(box, 8.0, 8.0, 0.1)
 prm.skin = prm.skin_min = 0.3
 refs = {}
