@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 7      /* 7 (round 5): the halo buffers' header (update written by the force pass), sph_slab_step + sph_slab_set_peer_links,
+#define SPH_ABI_VERSION 8      /* 8 (round 6): sph_slab_steps (runs of lean steps as graphs); 7 (round 5): the halo buffers' header (update written by the force pass), sph_slab_step + sph_slab_set_peer_links,
                                  * sph_set_rebuild_launches(ctx, N > 1) = a capped grid, verification on slab contexts */
 
 typedef enum sph_error {
@@ -324,6 +324,14 @@ typedef struct sph_peer_links {
 } sph_peer_links;
 int  sph_slab_set_peer_links(sph_ctx *ctx, const sph_peer_links *links);      /* between steps; NULL: none */
 int  sph_slab_step(sph_ctx *ctx, float gx, float gy);
+/* nsteps lean steps in one call (round 6, ABI v8): step s runs under gravity (gravity_xy[2 s], gravity_xy[2 s + 1]) — the host polls its
+ * gravity source for every step up front (the reference re-reads g every step, :632; a 10 Hz source changes it every ~400 steps).
+ * Runs of 16 / 8 / 4 / 2 steps are replayed as captured graphs — the four launches of a step take the step's number, the parity of its
+ * receive buffers and its gravity from device memory, so nothing in a launch changes from step to step — and what is left goes through
+ * sph_slab_step (also the first step after creation or an upload).  Same kernels, same results as nsteps calls of sph_slab_step (bitwise
+ * with sph_params.deterministic); with links every rank must call it with the same nsteps.  Between a launch's kernels no host is
+ * involved any more: one slab of 2 M particles through the C host runs at 0.9x of sph_step instead of 0.83. */
+int  sph_slab_steps(sph_ctx *ctx, const float *gravity_xy, int nsteps);
 /* bytes of one halo buffer of a slab created with these parameters and this halo_capacity (0 = default): what a host
  * needs to know before it creates the context (shared-memory transports size their mailboxes with it) */
 size_t sph_slab_halo_bytes(const sph_params *prm, int halo_capacity);

@@ -35,6 +35,14 @@ struct sph_ctx {
     bool has_links = false;      // sph_slab_set_peer_links: the lean step (sph_slab_step) talks to the other ranks itself
     sph_peer_links links{};
     uint32_t lean_step = 0;      // steps taken by sph_slab_step / counted by the device (FLAG_STEP): the tags of its messages
+    // sph_slab_steps: the gravity samples of a graphed run of steps (device: 2 x MULTI_STEPS floats, read by the head kernels of the
+    // graph's nodes; host: a ring of pinned staging slots, an event per slot; what the device holds now)
+    float *d_gseq = nullptr, *h_gseq = nullptr;
+    float h_gseq_last[2 * 64] = {};
+    bool gseq_valid = false, gseq_used[8] = {};
+    hipEvent_t gseq_ev[8] = {};
+    unsigned gseq_slot = 0;
+    bool step_done_synced = true;   // FLAG_STEP_DONE == FLAG_STEP between steps (k_rebuild_slab keeps it; the per-phase kernels do not)
     bool own_halo = false;      // halo buffers allocated by the library (else adopted from the host framework)
     size_t halo_bytes = 0;
     uint32_t *d_ids = nullptr;  // slab read-back staging
@@ -81,6 +89,7 @@ namespace {
 // concurrently (two contexts stepped from one host thread, each on its own stream) could each hold half the device and
 // wait for the other half: a context that finds company on its device goes back to one kernel per phase.
 constexpr int MAX_DEVICES = 64;
+constexpr int GSEQ_SLOTS = 8;      // pinned staging slots of sph_slab_steps' gravity samples
 std::atomic<int> g_live_contexts[MAX_DEVICES];
 bool device_shared(const sph_ctx *ctx);
 
@@ -500,6 +509,9 @@ void sph_destroy(sph_ctx *ctx) {
     drop_graph(ctx);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->gseq_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->h_gseq) (void)hipHostFree(ctx->h_gseq);
     for (void *p : ctx->allocs) (void)hipFree(p);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -591,6 +603,9 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(bpos_in, nb); ALLOC(bvel_in, nb); ALLOC(bkey, nb); ALLOC(ctx->d_bpsi0, nb); ALLOC(ctx->d_bcell_ids, nb);
     a.send[0] = a.send[1] = a.recv[0] = a.recv[1] = nullptr;
     if (slab) {
+        ALLOC(ctx->d_gseq, 2 * MULTI_STEPS);
+        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_gseq), sizeof(float) * 2 * MULTI_STEPS * GSEQ_SLOTS, hipHostMallocDefault));
+        for (auto &e : ctx->gseq_ev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->halo_bytes = sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * slab->halo_cap);
         for (int k = 0; k < 2; k++) { ALLOC(a.send[k], ctx->halo_bytes / 4); ALLOC(a.recv[k], ctx->halo_bytes / 4); }
         ctx->own_halo = true;
@@ -1369,6 +1384,7 @@ int sph_slab_step_end(sph_ctx *ctx) {
     if (ctx->rebuild_wgs > 0) {      // the host asked for it (sph_set_rebuild_launches): nothing else computes on the device meanwhile
         launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic);
     } else {
+        ctx->step_done_synced = false;                              // (FLAG_STEP_DONE is k_rebuild_slab's to keep: sph_slab_steps catches up)
         launch_halo_in(st, ctx->c, ctx->a, ctx->cap);               // rebuild step: ingest (then the next four); else ghost update
         launch_scan(st, ctx->c, ctx->a.count, ctx->a.dirty, ctx->a.cell_start, ctx->a.block_sums, ctx->a.rebuild, false);
         launch_reorder(st, ctx->c, ctx->a, ctx->cap, ctx->deterministic);
@@ -1392,6 +1408,7 @@ int sph_slab_set_peer_links(sph_ctx *ctx, const sph_peer_links *links) {
     if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_set_peer_links mid-step");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graph(ctx);      // (the links are arguments of the captured head / rebuild launches: sph_slab_steps)
     if (!links) { ctx->has_links = false; return SPH_OK; }
     if (links->n_ranks < 1 || links->n_ranks > SPH_PEER_MAX_RANKS || links->me < 0 || links->me >= links->n_ranks)
         return fail(ctx, SPH_E_ARG, "sph_slab_set_peer_links: rank out of range");
@@ -1425,14 +1442,98 @@ static void test_stall_after_head(int me, uint32_t step) {
 static inline void test_stall_after_head(int, uint32_t) {}
 #endif
 
+namespace {
+// what the two kernels of the lean step that talk to the other ranks need of the links.  step = 0: a node of a graph — the kernels take
+// the step's number (and with it the parity of the buffers) from the device (FLAG_STEP_DONE / FLAG_STEP, sph_internal.h).
+bool fill_peer(sph_ctx *ctx, uint32_t step, PeerHead &ph, PeerLinks &pl) {
+    const sph_peer_links &L = ctx->links;
+    const bool peer = ctx->has_links && L.n_ranks > 1;
+    ph = PeerHead{};
+    pl = PeerLinks{};
+    ph.nranks = 1;
+    ph.step = pl.step = step;
+    if (!peer) return false;
+    for (int q = 0; q < L.n_ranks; q++) ph.slots_of_rank[q] = static_cast<uint32_t *>(L.slots_of_rank[q]);
+    ph.my_slots = static_cast<const uint32_t *>(L.slots_of_rank[L.me]);
+    ph.me = L.me;
+    ph.nranks = L.n_ranks;
+    for (int par = 0; par < 2; par++) {
+        if (ctx->c.has_left) {
+            ph.remote_l[par] = pl.remote_l[par] = static_cast<uint32_t *>(L.left_recv[par]);
+            pl.recv_l[par] = static_cast<uint32_t *>(L.my_recv_left[par]);
+        }
+        if (ctx->c.has_right) {
+            ph.remote_r[par] = pl.remote_r[par] = static_cast<uint32_t *>(L.right_recv[par]);
+            pl.recv_r[par] = static_cast<uint32_t *>(L.my_recv_right[par]);
+        }
+    }
+    if (ctx->c.has_left) {
+        ph.flag_l = pl.flag_l = static_cast<uint32_t *>(L.left_flag);
+        pl.my_flag_l = static_cast<const uint32_t *>(L.my_flag_left);
+    }
+    if (ctx->c.has_right) {
+        ph.flag_r = pl.flag_r = static_cast<uint32_t *>(L.right_flag);
+        pl.my_flag_r = static_cast<const uint32_t *>(L.my_flag_right);
+    }
+    return true;
+}
+
+// the four launches of one lean step; gravity: this step's (gx, gy) as launch arguments (one call per step), or gravity_dev: where the
+// head kernel finds them in device memory (a node of a graph)
+void enqueue_lean_step(sph_ctx *ctx, const float *gravity, const float *gravity_dev, uint32_t step, bool stall_hook) {
+    hipStream_t st = ctx->stream;
+    PeerHead ph;
+    PeerLinks pl;
+    const bool peer = fill_peer(ctx, step, ph, pl);
+    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph, slab_verifies(ctx), ctx->slab_verify_most, gravity_dev);                 // 1
+    if (peer && stall_hook) test_stall_after_head(ctx->links.me, step);
+    launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 3 : 1, peer ? &pl : nullptr);   // 2
+    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, DENS_ALL, false);       // 3
+    launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);                            // 4
+}
+
+int lean_step_ready(sph_ctx *ctx, const char *who) {
+    if (!ctx->slab || ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, (std::string(who) + ": not a slab context, or mid-step").c_str());
+    if (ctx->rebuild_wgs <= 0)
+        return fail(ctx, SPH_E_STATE, (std::string(who) + " needs the one-launch rebuild: sph_set_rebuild_launches(ctx, 1) (nothing else may compute on the device)").c_str());
+    if (!fused(ctx)) return fail(ctx, SPH_E_STATE, (std::string(who) + ": list kernels only (variant 0)").c_str());
+    if ((ctx->c.has_left || ctx->c.has_right) && !ctx->has_links)
+        return fail(ctx, SPH_E_STATE, (std::string(who) + ": this slab has neighbours: sph_slab_set_peer_links first (or the three-call step with a transport of the host's)").c_str());
+    return SPH_OK;
+}
+
+// 2^k consecutive lean steps (primed loop) as ONE graph for the current orientation of the two position / velocity sets: every launch
+// takes its step number, the parity of its buffers and its gravity from device memory (gravity of step s of the run: d_gseq[2 s ..])
+hipGraphExec_t lean_graph(sph_ctx *ctx, int steps) {
+    if (!ctx->use_graph || steps < 2 || steps > MULTI_STEPS || (steps & (steps - 1)) != 0) return nullptr;
+    const int k = 2 * (31 - __builtin_clz((unsigned)steps)) + (ctx->a.pos == ctx->pos_a ? 0 : 1);
+    if (ctx->gexec[k]) return ctx->gexec[k];
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->use_graph = false;
+        return nullptr;
+    }
+    for (int s = 0; s < steps; s++) {
+        std::swap(ctx->a.pos, ctx->a.pos2);
+        std::swap(ctx->a.vel, ctx->a.vel2);
+        enqueue_lean_step(ctx, nullptr, ctx->d_gseq + 2 * s, 0u, false);
+    }
+    hipError_t e = hipStreamEndCapture(ctx->stream, &ctx->graph[k]);
+    if (e == hipSuccess) e = hipGraphInstantiate(&ctx->gexec[k], ctx->graph[k], nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        drop_graph(ctx);
+        ctx->use_graph = false;
+        return nullptr;
+    }
+    return ctx->gexec[k];
+}
+}  // namespace
+
 int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;
-    if (!ctx->slab || ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_step: not a slab context, or mid-step");
-    if (ctx->rebuild_wgs <= 0)
-        return fail(ctx, SPH_E_STATE, "sph_slab_step needs the one-launch rebuild: sph_set_rebuild_launches(ctx, 1) (nothing else may compute on the device)");
-    if (!fused(ctx)) return fail(ctx, SPH_E_STATE, "sph_slab_step: list kernels only (variant 0)");
-    if ((ctx->c.has_left || ctx->c.has_right) && !ctx->has_links)
-        return fail(ctx, SPH_E_STATE, "sph_slab_step: this slab has neighbours: sph_slab_set_peer_links first (or the three-call step with a transport of the host's)");
+    int rc = lean_step_ready(ctx, "sph_slab_step");
+    if (rc) return rc;
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     // kick 1/2 + drift of the owned range: the previous step's force pass made it (swap the sets), else the stand-alone kernel;
@@ -1446,40 +1547,70 @@ int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
     }
     ctx->primed = true;
     const uint32_t step = ++ctx->lean_step, par = step & 1u;
-    const sph_peer_links &L = ctx->links;
-    const bool peer = ctx->has_links && L.n_ranks > 1;
-    PeerHead ph = {};
-    PeerLinks pl = {};
-    ph.nranks = 1;
-    ph.step = pl.step = step;
-    if (peer) {
-        for (int q = 0; q < L.n_ranks; q++) ph.slots_of_rank[q] = static_cast<uint32_t *>(L.slots_of_rank[q]);
-        ph.my_slots = static_cast<const uint32_t *>(L.slots_of_rank[L.me]);
-        ph.me = L.me;
-        ph.nranks = L.n_ranks;
-        if (ctx->c.has_left) {
-            ph.remote_l = pl.remote_l = static_cast<uint32_t *>(L.left_recv[par]);
-            ph.flag_l = pl.flag_l = static_cast<uint32_t *>(L.left_flag);
-            pl.my_flag_l = static_cast<const uint32_t *>(L.my_flag_left);
-            ctx->a.recv[0] = static_cast<uint32_t *>(L.my_recv_left[par]);
-        }
-        if (ctx->c.has_right) {
-            ph.remote_r = pl.remote_r = static_cast<uint32_t *>(L.right_recv[par]);
-            ph.flag_r = pl.flag_r = static_cast<uint32_t *>(L.right_flag);
-            pl.my_flag_r = static_cast<const uint32_t *>(L.my_flag_right);
-            ctx->a.recv[1] = static_cast<uint32_t *>(L.my_recv_right[par]);
-        }
+    if (ctx->has_links && ctx->links.n_ranks > 1) {      // (what sph_slab_buffers reports: the receive buffers of this step's parity)
+        if (ctx->c.has_left) ctx->a.recv[0] = static_cast<uint32_t *>(ctx->links.my_recv_left[par]);
+        if (ctx->c.has_right) ctx->a.recv[1] = static_cast<uint32_t *>(ctx->links.my_recv_right[par]);
     }
     const float gravity[2] = {gx, gy};
-    launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph, slab_verifies(ctx), ctx->slab_verify_most);                     // 1
-    if (peer) test_stall_after_head(L.me, step);
-    launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 3 : 1, peer ? &pl : nullptr);   // 2
-    launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, true, DENS_ALL, false);       // 3
-    launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);                            // 4
+    enqueue_lean_step(ctx, gravity, nullptr, step, true);
     ctx->velt_stale = true;
     ctx->acc_stale = true;
     ctx->p_stale = true;
     ctx->stepped = true;
+    HIPCHK(ctx, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_slab_steps(sph_ctx *ctx, const float *gravity_xy, int nsteps) {
+    if (!ctx || !ctx->stream || nsteps < 0 || (nsteps > 0 && !gravity_xy)) return SPH_E_ARG;
+    int rc = lean_step_ready(ctx, "sph_slab_steps");
+    if (rc) return rc;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    int s = 0;
+    while (s < nsteps) {
+        int m = MULTI_STEPS;
+        while (m > nsteps - s) m >>= 1;
+        hipGraphExec_t g = ctx->primed && m >= 2 ? lean_graph(ctx, m) : nullptr;
+        if (!g) {      // the first step after creation / an upload (no look-ahead yet), a remainder of one step, or no graphs on this stream
+            rc = sph_slab_step(ctx, gravity_xy[2 * s], gravity_xy[2 * s + 1]);
+            if (rc) return rc;
+            s++;
+            continue;
+        }
+        // this run's gravity samples -> device (skipped while they repeat what is there: a 10 Hz gravity source changes every ~400 steps)
+        const float *gs = gravity_xy + 2 * s;
+        if (!ctx->gseq_valid || memcmp(ctx->h_gseq_last, gs, sizeof(float) * 2 * (size_t)m) != 0) {
+            const int slot = ctx->gseq_slot++ % GSEQ_SLOTS;
+            if (ctx->gseq_used[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->gseq_ev[slot]));      // (the copy that read this slot last has run)
+            float *h = ctx->h_gseq + (size_t)slot * 2 * MULTI_STEPS;
+            memcpy(h, gs, sizeof(float) * 2 * (size_t)m);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_gseq, h, sizeof(float) * 2 * (size_t)m, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipEventRecord(ctx->gseq_ev[slot], st));
+            ctx->gseq_used[slot] = true;
+            memcpy(ctx->h_gseq_last, gs, sizeof(float) * 2 * (size_t)m);
+            // (entries beyond m keep whatever an earlier, longer run left: a shorter run that matches the first m entries is still right,
+            // a longer one compares all of its own)
+            for (int k = 2 * m; k < 2 * MULTI_STEPS; k++) ctx->h_gseq_last[k] = NAN;
+            ctx->gseq_valid = true;
+        }
+        if (!ctx->step_done_synced) {      // (the three-call step with one kernel per phase does not keep FLAG_STEP_DONE)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->a.flags + FLAG_STEP_DONE, ctx->a.flags + FLAG_STEP, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            ctx->step_done_synced = true;
+        }
+        HIPCHK(ctx, hipGraphLaunch(g, st));
+        ctx->lean_step += (uint32_t)m;
+        if (ctx->has_links && ctx->links.n_ranks > 1) {      // (an even number of steps: the parity of the last one)
+            const uint32_t par = ctx->lean_step & 1u;
+            if (ctx->c.has_left) ctx->a.recv[0] = static_cast<uint32_t *>(ctx->links.my_recv_left[par]);
+            if (ctx->c.has_right) ctx->a.recv[1] = static_cast<uint32_t *>(ctx->links.my_recv_right[par]);
+        }
+        ctx->velt_stale = true;
+        ctx->acc_stale = true;
+        ctx->p_stale = true;
+        ctx->stepped = true;
+        s += m;
+    }
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }

@@ -182,6 +182,9 @@ enum {
                             //   reach of the lane's window bytes, (1) no free byte in the lane's rows, (2) the queue of repaired tiles is full
     FLAG_HEAD_GAVE_UP = 38, // k_slab_head: its exchange block gave up waiting for the criterion's blocks of its own launch (count); that step
                             //   went out as "rebuild": exact, reported by check_flags with a message of its own
+    FLAG_STEP_DONE = 39,    // slab contexts: FLAG_STEP as the last k_rebuild_slab found it = the step that launch belonged to.  Nobody writes it
+                            //   while a head kernel runs, so every block of k_slab_head can derive ITS step (this + 1) from the device alone:
+                            //   what lets 2^k lean steps be captured as one graph (sph_slab_steps)
     FLAG_PEER_DIAG = 40,    // + 0..3: the first peer wait that gave up: site (1 k_peer_reduce, 2 k_peer_wait, 3 head: rebuild word, 4 lean: update, 5 lean: records)
                             //   << 8 | side or rank, the tag it waited for, the word it saw last, this rank's step count
     FLAG_WORDS = 64
@@ -263,20 +266,26 @@ void launch_rebuild(hipStream_t st, const Consts &c, const Arrays &a, int cap, i
 // slab mode, what follows the halo exchange, as one launch: ghost update, or (rebuild step) ingest -> scan -> scatter ->
 // canonical order of the interface cells -> tile records + lists
 // the lean slab step (sph_slab_step): what its two kernels that talk to the other ranks need of the links (by value)
+// Round 6: both carry the buffers of BOTH parities and may leave the step number to the device (step = 0: k_slab_head takes
+// flags[FLAG_STEP_DONE] + 1, k_rebuild_slab flags[FLAG_STEP] — the head kernel of its step has counted it) — nothing in them then
+// changes from step to step, and a run of steps can be captured as one graph (sph_slab_steps).
 struct PeerHead {      // k_slab_head: k_check + the push of this step's update message + the MAX of the rebuild word
     uint32_t *slots_of_rank[SPH_PEER_MAX_RANKS];      // every rank's slot array (as in sph_slab_peer_reduce)
     const uint32_t *my_slots;
-    uint32_t *remote_l, *remote_r;                   // the neighbours' receive buffers of this step's parity (null: no neighbour)
+    uint32_t *remote_l[2], *remote_r[2];             // the neighbours' receive buffers by parity of the step (null: no neighbour)
     uint32_t *flag_l, *flag_r;                       // ... and their arrival flags
     int me, nranks;
-    uint32_t step;                                   // this step's number (flags[FLAG_STEP] once the kernel has counted it)
+    uint32_t step;                                   // this step's number (flags[FLAG_STEP] once the kernel has counted it); 0: from the device
 };
 struct PeerLinks {     // k_rebuild_slab, lean: wait for the update | exchange the records of a rebuild step inside the launch
-    uint32_t *remote_l, *remote_r, *flag_l, *flag_r;
+    uint32_t *remote_l[2], *remote_r[2], *flag_l, *flag_r;
+    uint32_t *recv_l[2], *recv_r[2];                 // this rank's own receive buffers by parity (null: Arrays::recv)
     const uint32_t *my_flag_l, *my_flag_r;           // this rank's own arrival flags (what its neighbours raise)
-    uint32_t step;
+    uint32_t step;                                   // 0: from the device
 };
-void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph, bool verify, int verify_most = 0);
+// gravity: the step's (gx, gy) as launch arguments — or gravity_dev (device memory, two floats) when the launch is a node of a graph
+void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph, bool verify, int verify_most = 0,
+                      const float *gravity_dev = nullptr);
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag);
 void launch_peer_push(hipStream_t st, const Consts &c, const Arrays &a, void *remote_l, void *flag_l, void *remote_r, void *flag_r, uint32_t tag);
 void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const void *flag_r, uint32_t tag);

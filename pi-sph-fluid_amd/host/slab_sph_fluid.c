@@ -29,7 +29,7 @@
  *   slab_sph_fluid --ranks N [--transport rccl|host|peer] [--scene dam|cfg3|cfg4|cfg4slab] [--block NX NY BOXW BOXH] [--origin X0 Y0]
  *                  [--velocity U V] [--steps K] [--warmup W] [--windows N] [--tilt] [--check] [--deterministic] [--skin F]
  *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE]
- *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--one-launch-wgs N] [--verify -1|0|1] [--repair -1|0|1]
+ *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--lean-graph 0|1] [--one-launch-wgs N] [--verify -1|0|1] [--repair -1|0|1]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
  * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
  * what may sit under a profiler; the launcher must not: see profiles/README.md).  The ncclUniqueId travels through a file
@@ -52,6 +52,9 @@
  * update message written by the force pass of the step before and everything between the ranks inside those kernels) where that is
  * possible: the peer transport, or a slab without neighbours, and the device this rank's alone (or --one-launch-wgs N: ranks that
  * share a device cap the grids of their one-launch kernels so that all of them stay resident — tests).  0: the three-call step.
+ * --lean-graph 1|0 (default 1, round 6): the lean steps between two things the HOST does (window boundaries, console lines, re-balancing)
+ * go to the library as ONE call per run of steps (sph_slab_steps: up to 16 steps per captured graph, their gravity samples in a device
+ * array, step number and buffer parity taken from the device); 0: sph_slab_step, one call of four launches per step.
  * --selfcomm (N = 1, rccl; a measurement): the all-reduce and the grouped send / receive of every step are issued anyway,
  * to this rank itself: what the RCCL calls of a step cost (enqueue + their kernels) before any neighbour is waited for.
  */
@@ -413,12 +416,14 @@ static float max_abs_diff(const sph_particle *a, const sph_particle *b, const un
 /* ------------------------------------------------------------------------------------------------------------------
  * one rank
  * ---------------------------------------------------------------------------------------------------------------- */
+#define LEAN_RUN_MAX 256      /* steps per sph_slab_steps call (the library cuts them into graphs of 16, 8, 4, 2 and single steps) */
 typedef struct rank_state {
     sph_params prm;
     comm cm;
     int device, transport, deterministic, capacity, halo_capacity;
     int own_device;              /* no other rank of this run on this rank's device (peer: as many devices as ranks) */
     int lean;                    /* the step is ONE call, sph_slab_step: four kernels, the exchange inside them (peer transport, or a slab alone) */
+    int lean_graph;              /* ... and runs of lean steps go to sph_slab_steps (graphs of up to 16 steps) */
     int verify, repair;          /* sph_set_verification / sph_set_list_repair: -1 automatic, 0 never, 1 always */
     int one_launch_wgs;          /* > 0: the one-launch kernels of this rank use at most so many workgroups (ranks sharing a device: they must all be resident) */
     sph_particle *walls;
@@ -733,6 +738,7 @@ int main(int argc, char **argv) {
     int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2, breakdown = 0, halo_capacity = -1;
     int repair_opt = -1;                        /* --repair -1 (default: from 4 000 000 particles per slab on) | 0 | 1: sph_set_list_repair */
     int verify_opt = -1;                        /* --verify -1 (default: the library's — slab contexts verify only when asked: 1) | 0 | 1: sph_set_verification */
+    int lean_graph_opt = 1;
     int lean_opt = -1, one_launch_wgs = 0;      /* --lean auto (-1) | 0 | 1; --one-launch-wgs N: cap of the one-launch kernels' grid (ranks that share a device) */
     float skin = -1;
     const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL;
@@ -763,6 +769,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--console")) console = 1;
         else if (!strcmp(argv[i], "--selfcomm")) selfcomm = 1;
         else if (!strcmp(argv[i], "--lean") && i + 1 < argc) { i++; lean_opt = !strcmp(argv[i], "auto") ? -1 : atoi(argv[i]); }
+        else if (!strcmp(argv[i], "--lean-graph") && i + 1 < argc) lean_graph_opt = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--one-launch-wgs") && i + 1 < argc) one_launch_wgs = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--verify") && i + 1 < argc) verify_opt = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--repair") && i + 1 < argc) repair_opt = atoi(argv[++i]);
@@ -883,6 +890,7 @@ int main(int argc, char **argv) {
         const int can = (rs.own_device || one_launch_wgs > 0) && !selfcomm && !deterministic_blocks_lean(deterministic) &&
                         (nranks == 1 || transport == TR_PEER);
         rs.lean = lean_opt < 0 ? can : (lean_opt && can);
+        rs.lean_graph = rs.lean && lean_graph_opt != 0;
         if (lean_opt > 0 && !can) { fprintf(stderr, "[rank %d] --lean 1 needs --transport peer (or one rank) and the device to itself (or --one-launch-wgs)\n", rank); return 2; }
     }
     HIPCHK(hipSetDevice(rs.device));
@@ -949,6 +957,29 @@ int main(int argc, char **argv) {
             t0 = now_s();
             win_t[0] = t0;
         }
+        /* lean step, graphed: everything up to the next thing the host does at a step boundary — the end of the warm-up or of a
+         * window, a re-balancing, the end of the run — as ONE call; the gravity source is polled for every step of the run up front,
+         * with the time of that step, exactly as the loop below does one step at a time (:632, :678) */
+        if (rs.lean_graph && !console && !rs.bd_on) {
+            int k = warmup + windows * steps - s;
+            if (s < warmup) k = warmup - s;
+            else if (steps > 0) { const int in_win = (s - warmup) % steps; if (steps - in_win < k) k = steps - in_win; }
+            if (rebalance_every) { const int to_rb = rebalance_every - s % rebalance_every; if (to_rb < k) k = to_rb; }
+            if (k > LEAN_RUN_MAX) k = LEAN_RUN_MAX;
+            if (k >= 2) {
+                static float gseq[2 * LEAN_RUN_MAX];
+                for (int j = 0; j < k; j++) {
+                    gseq[2 * j] = gx;
+                    gseq[2 * j + 1] = gy;
+                    t += prm.dt;
+                    sph_gravity_sample(&grav, t, &gx, &gy);
+                }
+                SPHCHK(rs.ctx, sph_slab_steps(rs.ctx, gseq, k));
+                s += k - 1;
+                if (rebalance_every && (s + 1) % rebalance_every == 0 && s + 1 < warmup + windows * steps) goto rebalance_now;
+                continue;
+            }
+        }
         CHK(step_once(&rs, gx, gy));
         t += prm.dt;                                                             /* :678 */
         if (console && t - last_t > 0.1f) {                                      /* the reference's console line, :679-691 */
@@ -972,6 +1003,7 @@ int main(int argc, char **argv) {
         }
         sph_gravity_sample(&grav, t, &gx, &gy);                                  /* 10 Hz hold, :455-461 */
         if (rebalance_every && (s + 1) % rebalance_every == 0 && s + 1 < warmup + windows * steps) {
+rebalance_now:;
             int rc = sph_sync(rs.ctx);                                           /* capacity / out-of-domain / NaN so far */
             if (rc) { fprintf(stderr, "[rank %d] sph_sync before re-balancing: %d (%s)\n", rank, rc, sph_last_error(rs.ctx)); return 1; }
             int moved = 0;
@@ -1090,7 +1122,7 @@ int main(int argc, char **argv) {
                "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s, "
                "\"halo_buffer_bytes\": %zu, \"breakdown_steps\": %d, \"per_rank\": [",
                transport == TR_RCCL ? "RCCL" : transport == TR_PEER ? "peer-mapped memory" : "host-staged shared memory",
-               rs.lean ? ", lean step: 4 kernels" : "", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
+               rs.lean ? (rs.lean_graph ? ", lean step: 4 kernels, graphs of up to 16 steps" : ", lean step: 4 kernels") : "", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
                steps, warmup, n_win, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
                n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false", rs.x.halo_bytes, bd_ok ? breakdown : 0);
         for (int r = 0; r < nranks; r++) {

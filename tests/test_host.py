@@ -29,7 +29,7 @@ def test_abi_library_loads_and_exports_every_declared_symbol(sph):
     hdecl = set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", hheader))
     for name in hdecl:
         assert hasattr(H, name), name
-    assert L.sph_abi_version() == 7
+    assert L.sph_abi_version() == 8
 
 
 def test_struct_layouts(sph):
