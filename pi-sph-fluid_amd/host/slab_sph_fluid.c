@@ -28,7 +28,8 @@
  *
  *   slab_sph_fluid --ranks N [--transport rccl|host|peer] [--scene dam|cfg3|cfg4|cfg4slab] [--block NX NY BOXW BOXH] [--origin X0 Y0]
  *                  [--velocity U V] [--steps K] [--warmup W] [--windows N] [--tilt] [--check] [--deterministic] [--skin F]
- *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE]
+ *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE] [--dump-accel FILE]
+ *                  [--dump-before STATE_FILE ACCEL_FILE]      (the state and accelerations in front of the last step: tests pin ONE slab step to the oracle)
  *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--lean-graph 0|1] [--one-launch-wgs N] [--verify -1|0|1] [--repair -1|0|1]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
  * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
@@ -570,6 +571,41 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
     return 0;
 }
 
+/* every rank's owned particles (records of sph_particle) and / or their accelerations (du_dt, dv_dt: two floats) into one file each, by
+ * global id: rank 0 makes the files, then everybody writes its records in place.  Between steps (sph_slab_read recomputes what the fused
+ * step does not store — the velocity between steps, the acceleration — without touching what the next step reads).  Collective. */
+static int dump_owned(rank_state *rs, const char *state_file, const char *accel_file, long n_total) {
+    int n_local = 0, n_owned = 0, n_out = 0;
+    SPHCHK(rs->ctx, sph_slab_counts(rs->ctx, &n_local, &n_owned));
+    sph_particle *got = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)(n_owned + 1));
+    unsigned *gid = (unsigned *)malloc(sizeof(unsigned) * (size_t)(n_owned + 1));
+    float *du = (float *)malloc(sizeof(float) * (size_t)(n_owned + 1)), *dv = (float *)malloc(sizeof(float) * (size_t)(n_owned + 1));
+    if (!got || !gid || !du || !dv) return 1;
+    SPHCHK(rs->ctx, sph_slab_read(rs->ctx, got, gid, du, dv, n_owned, &n_out));
+    const char *files[2] = {state_file, accel_file};
+    const size_t rec[2] = {sizeof(sph_particle), 2 * sizeof(float)};
+    for (int f = 0; f < 2; f++) {
+        if (!files[f]) continue;
+        if (rs->cm.rank == 0) {
+            FILE *fh = fopen(files[f], "wb");
+            if (!fh || ftruncate(fileno(fh), (off_t)(rec[f] * (size_t)n_total)) != 0) { fprintf(stderr, "cannot write %s\n", files[f]); return 1; }
+            fclose(fh);
+        }
+        CHK(comm_barrier(&rs->cm));
+        const int fd = open(files[f], O_WRONLY);
+        if (fd < 0) { fprintf(stderr, "[rank %d] cannot open %s\n", rs->cm.rank, files[f]); return 1; }
+        for (int k = 0; k < n_out; k++) {
+            const float a2[2] = {du[k], dv[k]};
+            const void *src = f == 0 ? (const void *)&got[k] : (const void *)a2;
+            if (pwrite(fd, src, rec[f], (off_t)(rec[f] * (size_t)gid[k])) != (ssize_t)rec[f]) return 1;
+        }
+        close(fd);
+        CHK(comm_barrier(&rs->cm));
+    }
+    free(got); free(gid); free(du); free(dv);
+    return 0;
+}
+
 /* one time step (:612-641) of this rank's slab */
 #define BD(k) do { if (rs->bd_on) HIPCHK(hipEventRecord(rs->bev[k], rs->st)); } while (0)
 static int step_once(rank_state *rs, float gx, float gy) {
@@ -741,7 +777,7 @@ int main(int argc, char **argv) {
     int lean_graph_opt = 1;
     int lean_opt = -1, one_launch_wgs = 0;      /* --lean auto (-1) | 0 | 1; --one-launch-wgs N: cap of the one-launch kernels' grid (ranks that share a device) */
     float skin = -1;
-    const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL;
+    const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL, *accel_file = NULL, *before_file = NULL, *before_accel_file = NULL;
     scene_t sc = {0, 0, 0.3f, 0.3f, 0, 0, 0, 0, NULL};
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--ranks") && i + 1 < argc) nranks = atoi(argv[++i]);
@@ -765,6 +801,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--breakdown") && i + 1 < argc) breakdown = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--frame") && i + 1 < argc) frame_file = argv[++i];
         else if (!strcmp(argv[i], "--dump-state") && i + 1 < argc) state_file = argv[++i];
+        else if (!strcmp(argv[i], "--dump-accel") && i + 1 < argc) accel_file = argv[++i];
+        else if (!strcmp(argv[i], "--dump-before") && i + 2 < argc) { before_file = argv[++i]; before_accel_file = argv[++i]; }
         else if (!strcmp(argv[i], "--tilt")) tilt = 1;
         else if (!strcmp(argv[i], "--console")) console = 1;
         else if (!strcmp(argv[i], "--selfcomm")) selfcomm = 1;
@@ -935,6 +973,10 @@ int main(int argc, char **argv) {
     double win_t[65];                 /* the clock at the start of every timed window and at the end of the last */
     int n_win = 0;
     for (int s = 0; s < warmup + windows * steps; s++) {
+        if (before_file && s == warmup + windows * steps - 1) {           /* --dump-before: the state (and accelerations) in front of the LAST step */
+            HIPCHK(hipStreamSynchronize(rs.st));
+            CHK(dump_owned(&rs, before_file, before_accel_file, n_total));
+        }
         if (s > warmup && steps > 0 && (s - warmup) % steps == 0) {      /* a window ends, the next begins: every rank, like t0 below */
             HIPCHK(hipStreamSynchronize(rs.st));
             HIPCHK(hipStreamSynchronize(rs.xst));
@@ -965,6 +1007,7 @@ int main(int argc, char **argv) {
             if (s < warmup) k = warmup - s;
             else if (steps > 0) { const int in_win = (s - warmup) % steps; if (steps - in_win < k) k = steps - in_win; }
             if (rebalance_every) { const int to_rb = rebalance_every - s % rebalance_every; if (to_rb < k) k = to_rb; }
+            if (before_file && s + k == warmup + windows * steps) k--;      /* (the last step on its own: the state in front of it is dumped) */
             if (k > LEAN_RUN_MAX) k = LEAN_RUN_MAX;
             if (k >= 2) {
                 static float gseq[2 * LEAN_RUN_MAX];
@@ -1137,27 +1180,8 @@ rebalance_now:;
     }
     if (owned_total != (long long)n_total) { fprintf(stderr, "[rank %d] particles lost: %lld of %ld\n", rank, owned_total, n_total); return 1; }
 
-    /* ---- --dump-state: every rank's owned particles into one file, by global id (records of sph_particle) ---- */
-    if (state_file) {
-        sph_particle *got = (sph_particle *)malloc(sizeof(sph_particle) * (size_t)(n_owned + 1));
-        unsigned *gid = (unsigned *)malloc(sizeof(unsigned) * (size_t)(n_owned + 1));
-        int n_out = 0;
-        if (!got || !gid) return 1;
-        SPHCHK(rs.ctx, sph_slab_read(rs.ctx, got, gid, NULL, NULL, n_owned, &n_out));
-        if (rank == 0) {                               /* rank 0 makes the file, then everybody writes its records in place */
-            FILE *fh = fopen(state_file, "wb");
-            if (!fh || ftruncate(fileno(fh), (off_t)(sizeof(sph_particle) * (size_t)n_total)) != 0) { fprintf(stderr, "cannot write %s\n", state_file); return 1; }
-            fclose(fh);
-        }
-        CHK(comm_barrier(&rs.cm));
-        const int fd = open(state_file, O_WRONLY);
-        if (fd < 0) { fprintf(stderr, "[rank %d] cannot open %s\n", rank, state_file); return 1; }
-        for (int k = 0; k < n_out; k++)
-            if (pwrite(fd, &got[k], sizeof(sph_particle), (off_t)(sizeof(sph_particle) * (size_t)gid[k])) != (ssize_t)sizeof(sph_particle)) return 1;
-        close(fd);
-        CHK(comm_barrier(&rs.cm));
-        free(got); free(gid);
-    }
+    /* ---- --dump-state [--dump-accel]: every rank's owned particles into one file, by global id ---- */
+    if (state_file || accel_file) CHK(dump_owned(&rs, state_file, accel_file, n_total));
 
     /* ---- --check (one rank): the same run through sph_step on a single context ---- */
     if (check) {

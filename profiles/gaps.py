@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/gaps.py <trace_kernel_trace.csv> [first_step] [nsteps] — the timeline of a few consecutive steps out of a
+"""profiles/gaps.py <trace_kernel_trace.csv> [first_step] [nsteps] [first kernel of a step: k_check | k_slab_head | k_density_list ...] — the timeline of a few consecutive steps out of a
 rocprofv3 --kernel-trace: per kernel its duration and the idle gap in front of it (end of the previous kernel on the
 stream to its start), and per step the sum of kernel time, of gaps, and the step's span.  A step = everything from one
 k_check launch to the next."""
@@ -17,7 +17,8 @@ def main():
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    starts = [k for k, r in enumerate(rows) if r[2] == "k_check"]
+    head = sys.argv[4] if len(sys.argv) > 4 else "k_check"
+    starts = [k for k, r in enumerate(rows) if r[2].startswith(head)]
     first = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
     nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     tot_k = tot_g = tot_span = 0.0

@@ -472,7 +472,7 @@ def test_speculative_pass_survives_waves_that_leave_early(sph):
         assert (out["list_repairs"][0] == 0) if no_repair else (sum(out["list_repairs"]) >= 0)
 
 
-def test_missing_pairs_are_appended_to_the_lists_instead_of_a_rebuild(sph, orc):
+def test_missing_pairs_are_appended_to_the_lists_instead_of_a_rebuild(sph, orc, oracle):
     """List repair (round 5).  A jittered lattice in which one particle in five flies at up to 40 m/s: pairs that were beyond the list
     cut-off when the lists were built come inside the support within a few steps.  The verification finds them — and appends them
     to the two lists they are missing from (list_add) instead of asking for the rebuild of everything; the gate repeats the density
@@ -507,4 +507,39 @@ def test_missing_pairs_are_appended_to_the_lists_instead_of_a_rebuild(sph, orc):
                 got = ctx.read_particles()
                 assert np.all(np.isfinite(got["x"])) and np.all(np.isfinite(got["rho"]))
                 assert (rep[0] > 0) == repair, rep
+                if repair:
+                    repaired_lists_vs_oracle(sph, orc, oracle, ctx, prm, walls)
     assert rebuilds[True] < rebuilds[False], rebuilds
+
+
+def repaired_lists_vs_oracle(sph, orc, oracle, ctx, prm, walls):
+    """Round 6 (the lists_vs_exact_walk checks above compare two variants of the same library): step until ONE step has appended pairs to
+    lists that it did not rebuild, then hold the state that step left — rho from its own density pass, LIVE through the repaired lists,
+    p, and the acceleration of its force pass — against the oracle on the same inputs: G1, G2, G3 at 1e-5 (pi_sph_fluid.c:263-289,
+    :294-301, :303-373)."""
+    from conftest import B_EOS
+    p = oracle.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
+    ob = walls.view(orc.PARTICLE).copy()
+    oracle.psi(p, ob)
+    for _ in range(60):
+        r0, rep0 = ctx.rebuild_stats()[0], ctx.repair_stats()[0]
+        ctx.step(1, 0.0, 0.0)
+        ctx.sync()
+        if ctx.rebuild_stats()[0] == r0 and ctx.repair_stats()[0] > rep0:
+            break
+    else:
+        raise AssertionError("no step repaired lists without rebuilding them")
+    got = ctx.read_particles()
+    du, dv = ctx.read_accel()
+    half = 0.5 * float(np.float32(prm.dt))
+    s = got.view(orc.PARTICLE).copy()
+    oracle.eval(p, s, ob, 0.0, 0.0, flags=1, threads=8)
+    assert np.max(np.abs(got["rho"] - s["rho"]) / s["rho"]) <= 1e-5                       # G1, live, through the repaired lists
+    s["rho"] = got["rho"]
+    oracle.eval(p, s, ob, 0.0, 0.0, flags=2, threads=8)
+    assert np.max(np.abs(got["p"] - s["p"]) / (s["p"] + B_EOS)) <= 1e-5                    # G2
+    s["p"] = got["p"]
+    s["u"] = (got["u"].astype(np.float64) - half * du.astype(np.float64)).astype(np.float32)      # v_half: what the force pass read
+    s["v"] = (got["v"].astype(np.float64) - half * dv.astype(np.float64)).astype(np.float32)
+    adu, adv, sa = oracle.eval(p, s, ob, 0.0, 0.0, flags=4, threads=8, want_sum_abs=True)
+    assert np.max(np.hypot(du - adu, dv - adv) / (sa + 1e-3)) <= 1e-5                      # G3 (no gravity here: the scale is the sum of the terms)

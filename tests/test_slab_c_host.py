@@ -369,3 +369,49 @@ def test_c_host_rebalancing_keeps_a_migrating_flow_inside_capacity(sph, tmp_path
         ref = ctx.read_particles()
     assert max(np.abs(got["x"] - ref["x"]).max(), np.abs(got["y"] - ref["y"]).max()) <= 5e-4
     assert np.abs(ref["x"] - f["x"]).min() > 6.0                  # the block did fly: 30 m/s x 0.22 s
+
+
+@pytest.mark.gpu
+def test_c_host_graphed_lean_steps_equal_single_calls_bitwise(sph, tmp_path):
+    """sph_slab_steps (round 6): runs of 16 / 8 / 4 / 2 lean steps replayed as captured graphs — step number, buffer parity and gravity
+    taken from device memory — against sph_slab_step, one call of four launches per step: three ranks over the peer transport on one
+    GPU, the adaptive skin (most steps carry updates, some rebuild), the tilt trace (gravity changes between runs of steps),
+    deterministic order: the same rebuild steps and the same bits.  1 + 163 + 120 steps: runs that are no multiple of anything."""
+    states = []
+    for graph in (1, 0):
+        state = tmp_path / ("state_g%d.bin" % graph)
+        r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--lean-graph", graph, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
+                                 "--velocity", 5, 0, "--steps", 163, "--warmup", 121, "--tilt", "--deterministic", "--dump-state", state])
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200
+        assert ("graphs of up to 16 steps" in rec["host"]) == bool(graph)
+        states.append((np.fromfile(state, sph.PARTICLE), rec["neighbour_rebuilds"]))
+    assert states[0][1] == states[1][1]
+    for k in ("x", "y", "u", "v", "rho", "p"):
+        assert np.array_equal(states[0][0][k], states[1][0][k]), k
+
+
+@pytest.mark.gpu
+def test_c_host_lean_step_state_and_last_step_vs_oracle(sph, orc, oracle, tmp_path):
+    """The lean step against the ORACLE (round 5's tests of it were bitwise against sph_step / the three-call step: transitive).  Two
+    ranks over the peer transport, graphed runs of steps, the block flying through the interface at 5 m/s with the default (adaptive)
+    skin: the C host dumps the gathered state and accelerations in front of the last step and behind it, and ONE oracle step from the
+    former must give the latter (conftest.fused_step_vs_oracle: x, v_half, rho, p, a, v and the acceleration the kick used: all
+    within 1e-5 on their scales) — the integration of a slab step, the ghosts' densities included, pinned to pi_sph_fluid.c:612-641."""
+    from conftest import fused_step_vs_oracle
+    fn = {k: tmp_path / (k + ".bin") for k in ("s0", "a0", "s1", "a1")}
+    r, out, rec = _run_host(["--ranks", 2, "--transport", "peer", "--lean", 1, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20, "--velocity", 5, 0,
+                             "--steps", 150, "--warmup", 50, "--dump-before", fn["s0"], fn["a0"], "--dump-state", fn["s1"], "--dump-accel", fn["a1"]])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200 and "graphs of up to 16 steps" in rec["host"]
+    before, after = np.fromfile(fn["s0"], sph.PARTICLE), np.fromfile(fn["s1"], sph.PARTICLE)
+    a0, a1 = np.fromfile(fn["a0"], np.float32).reshape(-1, 2), np.fromfile(fn["a1"], np.float32).reshape(-1, 2)
+    prm, f, b = _flying_block(sph, deterministic=False, skin=None)
+    assert len(before) == len(after) == len(f) == 90000
+    assert np.abs(before["x"] - f["x"]).min() > 0.1        # (the block has flown: 199 steps at 5 m/s = 0.24 m)
+    p = oracle.params((prm.x_min, prm.x_max, prm.y_min, prm.y_max))
+    ob = b.view(orc.PARTICLE).copy()
+    oracle.psi(p, ob)
+    worst = fused_step_vs_oracle(orc, oracle, p, ob, before, (a0[:, 0].copy(), a0[:, 1].copy()), after, (a1[:, 0].copy(), a1[:, 1].copy()),
+                                 (0.0, -9.81), float(np.float32(prm.dt)), tag="lean step, 2 ranks, peer")
+    assert max(worst.values()) <= 1.0, worst
