@@ -816,9 +816,10 @@ def slab_overhead(sph, out):
         if r.returncode != 0 or not lines:
             raise RuntimeError("slab_sph_fluid %s: exit %d: %s" % (" ".join(extra), r.returncode, r.stderr.decode(errors="replace")[-300:]))
         d = json.loads(lines[-1])
-        return {"timesteps_per_s": round(d["ticks_per_s"], 2), "window_timesteps_per_s": d.get("window_ticks_per_s"), "host": d["host"]}
+        return {"timesteps_per_s": round(d["ticks_per_s"], 2), "window_timesteps_per_s": d.get("window_ticks_per_s"), "host": d["host"],
+                "rebuilds_per_step_whole_run": round(d["neighbour_rebuilds"] / max(warmup + windows * steps, 1), 4)}
 
-    variants = [("lean", "sph_slab_step: 4 kernels, no neighbour", []),
+    variants = [("lean", "sph_slab_steps: 4 kernels per step, graphs of up to 16 steps, no neighbour", []),
                 ("three_call", "the three-call step: 6 kernels, no neighbour", ["--lean", "0"]),
                 ("three_call_rccl_selfcomm", "three-call + the step's RCCL calls (all-reduce, grouped send / receive) to the rank itself",
                  ["--lean", "0", "--selfcomm", "--transport", "rccl"]),
@@ -848,6 +849,31 @@ def slab_overhead(sph, out):
         size["strong_scaling_upper_bound_8_gpus"] = {k: round(size[k]["timesteps_per_s"] / t32, 2) for k, _w, _e in variants}
         size["strong_scaling_upper_bound_8_gpus"]["sph_step_on_the_slab"] = round(r1["steps_per_s"] / t32, 2)
     res["sizes"]["4M (one of cfg4's eight slabs, tilt trace, at rest)"] = size
+    # 4M DEVELOPED (round 6): the same tank once its lattice has fallen and bounced (the window of cfg4's developed leg) — the regime that
+    # decides the strong leg: rebuilds cost milliseconds there and a slab context rebuilds more often than sph_step (no verification by
+    # default, the absolute criterion next to ghosts).  One slab through the C host (lean, graphed) against sph_step on the same particles,
+    # and the bound t(32 M developed on one GPU) / t(its slab): what 8 GPUs can reach at most with everything between them hidden.
+    keyd, wu, st_, wn = STRONG_LEGS["developed"]
+    try:
+        r1 = run_single(sph, "cfg4_slab", st_, wu, profile_steps=5, tilt=True, windows=wn)
+        total = wu + wn * st_
+        size = {"n_fluid": r1["n_fluid"], "window": [wu, st_, wn], "sph_step_timesteps_per_s": round(r1["steps_per_s"], 2),
+                "sph_step_window_timesteps_per_s": r1["window_steps_per_s"], "sph_step_rebuilds_per_step_whole_run": round(r1["rebuilds"] / max(total + 5, 1), 4),
+                "sph_step_window_rebuilds_per_step": r1["window_rebuilds_per_step"]}
+        for key, what, extra in variants[:2]:
+            cmd_extra = extra
+            d = c_host("cfg4slab", wu, st_, wn, True, cmd_extra)
+            size[key] = dict(d, what=what, vs_sph_step=round(d["timesteps_per_s"] / r1["steps_per_s"], 4))
+            log("slab_overhead 4M developed %s: %s" % (key, size[key]))
+        t32 = next((e["timesteps_per_s"] for e in out.get("also", []) if e.get("cache_key") == keyd), None)
+        if t32:
+            size["cfg4_one_gpu_timesteps_per_s"] = t32
+            size["strong_scaling_upper_bound_8_gpus"] = {k: round(size[k]["timesteps_per_s"] / t32, 2) for k, _w, _e in variants[:2]}
+            size["strong_scaling_upper_bound_8_gpus"]["sph_step_on_the_slab"] = round(r1["steps_per_s"] / t32, 2)
+        res["sizes"]["4M developed (the same tank, steps %d-%d: the lattice has fallen)" % (wu, total)] = size
+    except Exception as e_:      # (reported, never raised)
+        log("slab_overhead 4M developed failed: %r" % (e_,))
+        res["sizes"]["4M developed"] = {"status": "failed: %r" % (e_,)}
     return res
 
 

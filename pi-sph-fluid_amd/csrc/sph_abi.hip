@@ -234,7 +234,10 @@ void enqueue_step_body(sph_ctx *ctx, hipEvent_t *ev) {
             ga.rq = nullptr;          // writes neither the remembered partners (8 B per particle) nor the spare row of padding (4 B): at
             ga.xpair = nullptr;       // 2 M particles 24 MB per rebuild that only a repair would read
         }
+#ifndef SPH_UNSAFE_NO_GATE      // (measurement build, results NOT exact once a rebuild is due — the bound for any scheme that drops the gate's launch
+                                // from steps that do not rebuild: make variant NAME=nogate VFLAGS=-DSPH_UNSAFE_NO_GATE)
         launch_rebuild(st, ctx->c, ga, ctx->cap, ctx->rebuild_wgs, false, ctx->deterministic, true);
+#endif
         launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);
         return;
     }

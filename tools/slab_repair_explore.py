@@ -17,14 +17,14 @@ L.sph_repair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 L.sph_rebuild_reasons.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 
 
-def scene(n_fast, speed, seed=11):
+def scene(n_fast, speed, jitter=0.02, seed=11):
     rng = np.random.default_rng(seed)
     box = (0.0, 16.0, 0.0, 16.0)
     prm = sph.default_params(box)
     nx, ny = 168, 40
     gx, gy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
     gx, gy = gx.ravel(), gy.ravel()
-    xy = np.array([1.7, 6.5]) + 0.075 * np.stack([gx, gy], 1) + rng.uniform(-0.02, 0.02, (nx * ny, 2))
+    xy = np.array([1.7, 6.5]) + 0.075 * np.stack([gx, gy], 1) + rng.uniform(-jitter, jitter, (nx * ny, 2)) if jitter > 0 else 0.0
     uv = np.zeros((nx * ny, 2))
     for lo, hi in ((30, 54), (114, 138)):      # the middle of either slab, well inside vertically
         cand = np.nonzero((gx >= lo) & (gx < hi) & (gy >= 10) & (gy < 30))[0]
@@ -40,8 +40,8 @@ def scene(n_fast, speed, seed=11):
     return prm, f, walls
 
 
-for n_fast, speed in ((1, 20.0), (4, 20.0), (12, 20.0), (12, 10.0), (40, 10.0), (40, 20.0)):
-    prm, f, walls = scene(n_fast, speed)
+for n_fast, speed, jitter in ((1, 20.0, 0.0), (12, 20.0, 0.0), (12, 20.0, 0.002), (40, 30.0, 0.0), (12, 20.0, 0.02)):
+    prm, f, walls = scene(n_fast, speed, jitter)
     for repair in (1, 0):
         parts = sph.slab.partition_columns(prm, f, 2, slack=8)
         slabs = [sph.slab.GpuSlab(sph, prm, f, walls, c0, c1, r > 0, r < 1, 0.0, 0.0) for r, (c0, c1) in enumerate(parts)]
@@ -62,6 +62,6 @@ for n_fast, speed in ((1, 20.0), (4, 20.0), (12, 20.0), (12, 10.0), (40, 10.0), 
                 reps.append(list(a))
                 reqs.append(list(w))
             line.append("@%d repairs %s rebuilds %d requests %s" % (upto, [r[0] for r in reps], slabs[0].rebuilds(), reqs))
-        print("n_fast %d speed %.0f repair %d: %s" % (n_fast, speed, repair, " | ".join(line)), flush=True)
+        print("n_fast %d speed %.0f jitter %.3f repair %d: %s" % (n_fast, speed, jitter, repair, " | ".join(line)), flush=True)
         for s_ in slabs:
             s_.close()
