@@ -332,6 +332,18 @@ int  sph_slab_step(sph_ctx *ctx, float gx, float gy);
  * with sph_params.deterministic); with links every rank must call it with the same nsteps.  Between a launch's kernels no host is
  * involved any more: one slab of 2 M particles through the C host runs at 0.9x of sph_step instead of 0.83. */
 int  sph_slab_steps(sph_ctx *ctx, const float *gravity_xy, int nsteps);
+/* the SPECULATIVE lean step (round 6; on = 1; default 0): what makes sph_step's neighbour lists last — failing boxes verified particle
+ * by particle, missing pairs appended — costs sph_step nothing because those jobs ride in the launch of a density pass that assumes the
+ * lists valid.  The plain lean step cannot do that (its head kernel must know the verdict before the word goes round), so a slab rebuilt
+ * 2.3 x as often as sph_step on the dam break (0.104 against 0.045 rebuilds per step: the whole of its deficit at 2 M particles).  With
+ * this switch the four launches of sph_slab_step / sph_slab_steps become
+ *     head      the books, the push of the update message, the wait for the neighbours' and the ghost update
+ *     density   speculative, the criterion's check / verify jobs in its launch (sph_set_verification decides as on a single context)
+ *     gate      the MAX of the rebuild word over the ranks (by its first workgroup; the others wait for it), then nothing — or the
+ *               rebuild of the plain lean step AND the density pass again on the new lists
+ *     force     as before
+ * Every rank of a run must use the same setting (the word is exchanged by different kernels). */
+int  sph_slab_set_speculative(sph_ctx *ctx, int on);
 /* bytes of one halo buffer of a slab created with these parameters and this halo_capacity (0 = default): what a host
  * needs to know before it creates the context (shared-memory transports size their mailboxes with it) */
 size_t sph_slab_halo_bytes(const sph_params *prm, int halo_capacity);

@@ -44,7 +44,7 @@ ABI_SYMBOLS = [      # include/sph.h: the drop-in boundary (+ slabs, metaballs)
     "sph_set_stream", "sph_device_bytes",
     "sph_render_metaballs",
     "sph_create_slab", "sph_slab_step_begin", "sph_slab_step_pack", "sph_slab_step_overlap", "sph_slab_step_overlap_on", "sph_slab_step_end",
-    "sph_slab_peer_reduce", "sph_slab_peer_push", "sph_slab_peer_wait", "sph_slab_set_peer_links", "sph_slab_step", "sph_slab_steps",
+    "sph_slab_peer_reduce", "sph_slab_peer_push", "sph_slab_peer_wait", "sph_slab_set_peer_links", "sph_slab_step", "sph_slab_steps", "sph_slab_set_speculative",
     "sph_slab_flag_buffer", "sph_slab_set_flag_buffer", "sph_slab_flag_get", "sph_slab_flag_set", "sph_slab_buffers", "sph_slab_set_buffers",
     "sph_slab_copy_out", "sph_slab_copy_in", "sph_slab_read", "sph_slab_counts", "sph_slab_halo_bytes",
 ]

@@ -42,6 +42,7 @@ struct sph_ctx {
     bool gseq_valid = false, gseq_used[8] = {};
     hipEvent_t gseq_ev[8] = {};
     unsigned gseq_slot = 0;
+    bool lean_spec = false;      // sph_slab_set_speculative: the lean step with the criterion inside the launch of a speculative density pass
     bool step_done_synced = true;   // FLAG_STEP_DONE == FLAG_STEP between steps (k_rebuild_slab keeps it; the per-phase kernels do not)
     bool own_halo = false;      // halo buffers allocated by the library (else adopted from the host framework)
     size_t halo_bytes = 0;
@@ -395,8 +396,9 @@ int upload_jobs(sph_ctx *ctx) {
     // Slab contexts repair too (the verification blocks of their head kernel, k_slab_head): their density pass runs after the head
     // kernel, on the repaired lists — there is nothing to repeat and no queue.
     const bool repair = list_repair(ctx);
-    uint32_t *rq = repair && !ctx->slab ? a.rq : nullptr;
-    const uint32_t repair_kind = !repair ? 0u : ctx->slab ? 2u : 1u;
+    const bool queued = !ctx->slab || ctx->lean_spec;      // (the density pass runs beside the repairs: their tiles are queued for a repeat)
+    uint32_t *rq = repair && queued ? a.rq : nullptr;
+    const uint32_t repair_kind = !repair ? 0u : queued ? 1u : 2u;
     const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, first, a.pos_ref, vfirst, a.uref,
                          a.tiles, a.nlist, a.stab, a.xranges, rq, a.xpair, repair_kind};
     SpecJobs j1 = j0;
@@ -589,7 +591,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     a.vq = nullptr;
     ALLOC(a.vq, 2 + 2 * (size_t)vq_capacity(ctx->cap));      // (slab contexts too: the verification blocks of their head kernel, k_slab_head)
     a.rq = nullptr;
-    if (!slab) { ALLOC(a.rq, RQ_CAP); }
+    ALLOC(a.rq, RQ_CAP);      // (slab contexts: the speculative lean step queues repaired tiles like sph_step)
     a.djobs[0] = a.djobs[1] = nullptr;
     a.pos_first = a.pos;
     ALLOC(a.djobs[0], 1); ALLOC(a.djobs[1], 1);
@@ -1456,10 +1458,10 @@ bool fill_peer(sph_ctx *ctx, uint32_t step, PeerHead &ph, PeerLinks &pl) {
     ph.nranks = 1;
     ph.step = pl.step = step;
     if (!peer) return false;
-    for (int q = 0; q < L.n_ranks; q++) ph.slots_of_rank[q] = static_cast<uint32_t *>(L.slots_of_rank[q]);
-    ph.my_slots = static_cast<const uint32_t *>(L.slots_of_rank[L.me]);
-    ph.me = L.me;
-    ph.nranks = L.n_ranks;
+    for (int q = 0; q < L.n_ranks; q++) ph.slots_of_rank[q] = pl.slots_of_rank[q] = static_cast<uint32_t *>(L.slots_of_rank[q]);
+    ph.my_slots = pl.my_slots = static_cast<const uint32_t *>(L.slots_of_rank[L.me]);
+    ph.me = pl.me = L.me;
+    ph.nranks = pl.nranks = L.n_ranks;
     for (int par = 0; par < 2; par++) {
         if (ctx->c.has_left) {
             ph.remote_l[par] = pl.remote_l[par] = static_cast<uint32_t *>(L.left_recv[par]);
@@ -1488,6 +1490,19 @@ void enqueue_lean_step(sph_ctx *ctx, const float *gravity, const float *gravity_
     PeerHead ph;
     PeerLinks pl;
     const bool peer = fill_peer(ctx, step, ph, pl);
+    if (ctx->lean_spec) {
+        // the speculative lean step: books + push + ghost update | density with the criterion's jobs in its launch (as sph_step) | the gate:
+        // MAX of the word over the ranks, then nothing, or the rebuild and the density pass again | force
+        launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph, false, 0, gravity_dev, true, peer ? &pl : nullptr);                  // 1
+        if (peer && stall_hook) test_stall_after_head(ctx->links.me, step);
+        launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_ALL, false, true,
+                       ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0);                                   // 2
+        Arrays ga = ctx->a;
+        if (!list_repair(ctx)) { ga.rq = nullptr; ga.xpair = nullptr; }
+        launch_rebuild_slab(st, ctx->c, ga, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 7 : 5, peer ? &pl : nullptr);       // 3
+        launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);                                                    // 4
+        return;
+    }
     launch_slab_head(st, ctx->c, ctx->a, ctx->cap, gravity, ph, slab_verifies(ctx), ctx->slab_verify_most, gravity_dev);                 // 1
     if (peer && stall_hook) test_stall_after_head(ctx->links.me, step);
     launch_rebuild_slab(st, ctx->c, ctx->a, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 3 : 1, peer ? &pl : nullptr);   // 2
@@ -1532,6 +1547,16 @@ hipGraphExec_t lean_graph(sph_ctx *ctx, int steps) {
     return ctx->gexec[k];
 }
 }  // namespace
+
+int sph_slab_set_speculative(sph_ctx *ctx, int on) {
+    if (!ctx || !ctx->stream || !ctx->slab || on < 0 || on > 1) return SPH_E_ARG;
+    if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_set_speculative mid-step");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graph(ctx);
+    ctx->lean_spec = on != 0;
+    return upload_jobs(ctx);      // (repaired tiles are queued for a repeat of their density only where a density pass runs beside the repairs)
+}
 
 int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
     if (!ctx || !ctx->stream) return SPH_E_ARG;

@@ -185,6 +185,7 @@ enum {
     FLAG_STEP_DONE = 39,    // slab contexts: FLAG_STEP as the last k_rebuild_slab found it = the step that launch belonged to.  Nobody writes it
                             //   while a head kernel runs, so every block of k_slab_head can derive ITS step (this + 1) from the device alone:
                             //   what lets 2^k lean steps be captured as one graph (sph_slab_steps)
+    FLAG_WORD_READY = 44,   // the speculative slab step (k_rebuild_slab, spec): the step whose reduced rebuild word workgroup 0 has published (grows)
     FLAG_PEER_DIAG = 40,    // + 0..3: the first peer wait that gave up: site (1 k_peer_reduce, 2 k_peer_wait, 3 head: rebuild word, 4 lean: update, 5 lean: records)
                             //   << 8 | side or rank, the tag it waited for, the word it saw last, this rank's step count
     FLAG_WORDS = 64
@@ -277,21 +278,32 @@ struct PeerHead {      // k_slab_head: k_check + the push of this step's update 
     int me, nranks;
     uint32_t step;                                   // this step's number (flags[FLAG_STEP] once the kernel has counted it); 0: from the device
 };
+// Round 6, the SPECULATIVE lean step (sph_slab_set_speculative): head = bookkeeping + push + the wait for the neighbours' update and the
+// ghost update (no criterion, no word exchange) | density, speculative, with the criterion's jobs in its launch as in sph_step | the
+// gate: MAX of the word over the ranks, then nothing — or the rebuild AND the density pass again | force.  PeerLinks then also carries
+// what the word exchange needs (slots).
 struct PeerLinks {     // k_rebuild_slab, lean: wait for the update | exchange the records of a rebuild step inside the launch
     uint32_t *remote_l[2], *remote_r[2], *flag_l, *flag_r;
     uint32_t *recv_l[2], *recv_r[2];                 // this rank's own receive buffers by parity (null: Arrays::recv)
     const uint32_t *my_flag_l, *my_flag_r;           // this rank's own arrival flags (what its neighbours raise)
     uint32_t step;                                   // 0: from the device
+    uint32_t *slots_of_rank[SPH_PEER_MAX_RANKS];     // (speculative step: the word exchange happens in k_rebuild_slab) as in PeerHead
+    const uint32_t *my_slots;
+    int me, nranks;
 };
 // gravity: the step's (gx, gy) as launch arguments — or gravity_dev (device memory, two floats) when the launch is a node of a graph
+// spec: the head of the speculative lean step — no criterion blocks, no word exchange; with links it also waits for the neighbours' update
+// and updates the ghosts (links: the receive buffers and own flags)
 void launch_slab_head(hipStream_t st, const Consts &c, const Arrays &a, int cap, const float *gravity, const PeerHead &ph, bool verify, int verify_most = 0,
-                      const float *gravity_dev = nullptr);
+                      const float *gravity_dev = nullptr, bool spec = false, const PeerLinks *links = nullptr);
 void launch_peer_reduce(hipStream_t st, const Arrays &a, void *const *slots_of_rank, const void *mine, int me, int nranks, uint32_t tag);
 void launch_peer_push(hipStream_t st, const Consts &c, const Arrays &a, void *remote_l, void *flag_l, void *remote_r, void *flag_r, uint32_t tag);
 void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const void *flag_r, uint32_t tag);
 // lean (sph_slab_step): bit 0 = the pack of a rebuild step (keys + histogram of the owned range, records into the send buffers) is
 // this launch's first phase instead of k_halo_out's; bit 1 = peer transport: the launch waits for the neighbours' update itself
 // and, on a rebuild step, pushes its records and waits for theirs between two of its grid barriers (links)
+// lean bit 2 (speculative lean step): the launch follows the speculative density pass — it exchanges the rebuild word itself (links->slots),
+// the ghost update has been done by the head kernel, and a rebuild ends with the density pass on the new lists
 void launch_rebuild_slab(hipStream_t st, const Consts &c, const Arrays &a, int cap, int grid, bool deterministic = false, int lean = 0,
                          const PeerLinks *links = nullptr);
 // raise the rebuild request: the next step rebuilds the neighbour structure

@@ -566,15 +566,17 @@ void launch_key_only(hipStream_t st, const Consts &c, const Arrays &a, int cap, 
 // particle id, k_canon), so the owner's two outermost owned columns and the neighbour's two ghost columns are the
 // SAME sequence of particles: the update is a plain copy of a contiguous range, 16 bytes per particle.
 // Buffer header: {count, kind, 0, 0}, kind 0 = full records (rebuild step), 1 = update.
+// expect_step: the step the message must be for — flags[FLAG_STEP] once the step's first kernel has counted it (0: read it), or the
+// number k_slab_head has derived for itself (its own block 0 counts the step while its other blocks run)
 DEV void unpack_update_body(const Consts &c, int side, int t, float2 *__restrict__ pos, float2 *__restrict__ vel,
                             const uint32_t *__restrict__ cs, uint32_t *__restrict__ flags, const uint32_t *__restrict__ recv_l,
-                            const uint32_t *__restrict__ recv_r) {
+                            const uint32_t *__restrict__ recv_r, const uint32_t expect_step = 0u) {
     if (side == 0 ? !c.has_left : !c.has_right) return;
     const int col0 = side == 0 ? 0 : c.ghost + c.owned;
     const int beg = (int)cs[col0 * c.rows], n = (int)cs[(col0 + c.ghost) * c.rows] - beg;
     const uint32_t *buf = side == 0 ? recv_l : recv_r;
     // the neighbour must have sent an update of exactly my ghost range (same rebuild step, same canonical order), for THIS step
-    if (t == 0 && (buf[HALO_UPD_COUNT] != (uint32_t)n || buf[HALO_UPD_STEP] != flags[FLAG_STEP])) atomicAdd(&flags[FLAG_MISMATCH], 1u);
+    if (t == 0 && (buf[HALO_UPD_COUNT] != (uint32_t)n || buf[HALO_UPD_STEP] != (expect_step ? expect_step : flags[FLAG_STEP]))) atomicAdd(&flags[FLAG_MISMATCH], 1u);
     if (t >= n || t >= (int)buf[HALO_UPD_COUNT]) return;
     const float4 q = reinterpret_cast<const float4 *>(buf + HALO_HDR)[t];
     pos[beg + t] = make_float2(q.x, q.y);

@@ -30,7 +30,7 @@
  *                  [--velocity U V] [--steps K] [--warmup W] [--windows N] [--tilt] [--check] [--deterministic] [--skin F]
  *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE] [--dump-accel FILE]
  *                  [--dump-before STATE_FILE ACCEL_FILE]      (the state and accelerations in front of the last step: tests pin ONE slab step to the oracle)
- *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--lean-graph 0|1] [--one-launch-wgs N] [--verify -1|0|1] [--repair -1|0|1]
+ *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--lean-graph 0|1] [--lean-spec 0|1] [--one-launch-wgs N] [--verify -1|0|1] [--repair -1|0|1]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
  * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
  * what may sit under a profiler; the launcher must not: see profiles/README.md).  The ncclUniqueId travels through a file
@@ -53,6 +53,8 @@
  * update message written by the force pass of the step before and everything between the ranks inside those kernels) where that is
  * possible: the peer transport, or a slab without neighbours, and the device this rank's alone (or --one-launch-wgs N: ranks that
  * share a device cap the grids of their one-launch kernels so that all of them stay resident — tests).  0: the three-call step.
+ * --lean-spec 0|1 (round 6): the SPECULATIVE lean step (sph_slab_set_speculative): the rebuild criterion — boxes, verification, list repair —
+ * inside the launch of a speculative density pass, as in sph_step; the word goes round in the gate kernel.
  * --lean-graph 1|0 (default 1, round 6): the lean steps between two things the HOST does (window boundaries, console lines, re-balancing)
  * go to the library as ONE call per run of steps (sph_slab_steps: up to 16 steps per captured graph, their gravity samples in a device
  * array, step number and buffer parity taken from the device); 0: sph_slab_step, one call of four launches per step.
@@ -425,6 +427,7 @@ typedef struct rank_state {
     int own_device;              /* no other rank of this run on this rank's device (peer: as many devices as ranks) */
     int lean;                    /* the step is ONE call, sph_slab_step: four kernels, the exchange inside them (peer transport, or a slab alone) */
     int lean_graph;              /* ... and runs of lean steps go to sph_slab_steps (graphs of up to 16 steps) */
+    int lean_spec;               /* ... and the lean step is the speculative one (sph_slab_set_speculative): the criterion inside the density launch */
     int verify, repair;          /* sph_set_verification / sph_set_list_repair: -1 automatic, 0 never, 1 always */
     int one_launch_wgs;          /* > 0: the one-launch kernels of this rank use at most so many workgroups (ranks sharing a device: they must all be resident) */
     sph_particle *walls;
@@ -553,6 +556,7 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
         if (desc.has_right) L.right_flag = (char *)rs->peer_of[me + 1] + peer_off_flag(rs, 0);
         SPHCHK(rs->ctx, sph_slab_set_peer_links(rs->ctx, &L));
     }
+    if (rs->lean && rs->lean_spec) SPHCHK(rs->ctx, sph_slab_set_speculative(rs->ctx, 1));
     SPHCHK(rs->ctx, sph_slab_flag_buffer(rs->ctx, &rs->flag));
     SPHCHK(rs->ctx, sph_slab_buffers(rs->ctx, &rs->x.send_l, &rs->x.send_r, &rs->x.recv_l, &rs->x.recv_r, &rs->x.halo_bytes));
     if (rs->transport == TR_PEER && rs->x.halo_bytes > rs->peer_halo) { fprintf(stderr, "[rank %d] halo buffers outgrew the peer block\n", rs->cm.rank); return 1; }
@@ -774,7 +778,7 @@ int main(int argc, char **argv) {
     int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2, breakdown = 0, halo_capacity = -1;
     int repair_opt = -1;                        /* --repair -1 (default: from 4 000 000 particles per slab on) | 0 | 1: sph_set_list_repair */
     int verify_opt = -1;                        /* --verify -1 (default: the library's — slab contexts verify only when asked: 1) | 0 | 1: sph_set_verification */
-    int lean_graph_opt = 1;
+    int lean_graph_opt = 1, lean_spec_opt = 0;
     int lean_opt = -1, one_launch_wgs = 0;      /* --lean auto (-1) | 0 | 1; --one-launch-wgs N: cap of the one-launch kernels' grid (ranks that share a device) */
     float skin = -1;
     const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL, *accel_file = NULL, *before_file = NULL, *before_accel_file = NULL;
@@ -808,6 +812,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--selfcomm")) selfcomm = 1;
         else if (!strcmp(argv[i], "--lean") && i + 1 < argc) { i++; lean_opt = !strcmp(argv[i], "auto") ? -1 : atoi(argv[i]); }
         else if (!strcmp(argv[i], "--lean-graph") && i + 1 < argc) lean_graph_opt = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--lean-spec") && i + 1 < argc) lean_spec_opt = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--one-launch-wgs") && i + 1 < argc) one_launch_wgs = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--verify") && i + 1 < argc) verify_opt = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--repair") && i + 1 < argc) repair_opt = atoi(argv[++i]);
@@ -929,6 +934,7 @@ int main(int argc, char **argv) {
                         (nranks == 1 || transport == TR_PEER);
         rs.lean = lean_opt < 0 ? can : (lean_opt && can);
         rs.lean_graph = rs.lean && lean_graph_opt != 0;
+        rs.lean_spec = rs.lean && lean_spec_opt != 0;
         if (lean_opt > 0 && !can) { fprintf(stderr, "[rank %d] --lean 1 needs --transport peer (or one rank) and the device to itself (or --one-launch-wgs)\n", rank); return 2; }
     }
     HIPCHK(hipSetDevice(rs.device));
@@ -1165,7 +1171,8 @@ rebalance_now:;
                "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s, "
                "\"halo_buffer_bytes\": %zu, \"breakdown_steps\": %d, \"per_rank\": [",
                transport == TR_RCCL ? "RCCL" : transport == TR_PEER ? "peer-mapped memory" : "host-staged shared memory",
-               rs.lean ? (rs.lean_graph ? ", lean step: 4 kernels, graphs of up to 16 steps" : ", lean step: 4 kernels") : "", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
+               rs.lean ? (rs.lean_spec ? (rs.lean_graph ? ", lean step: 4 kernels, speculative, graphs of up to 16 steps" : ", lean step: 4 kernels, speculative")
+                                       : (rs.lean_graph ? ", lean step: 4 kernels, graphs of up to 16 steps" : ", lean step: 4 kernels")) : "", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
                steps, warmup, n_win, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
                n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false", rs.x.halo_bytes, bd_ok ? breakdown : 0);
         for (int r = 0; r < nranks; r++) {

@@ -24,7 +24,7 @@ def scene(n_fast, speed, jitter=0.02, seed=11):
     nx, ny = 168, 40
     gx, gy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
     gx, gy = gx.ravel(), gy.ravel()
-    xy = np.array([1.7, 6.5]) + 0.075 * np.stack([gx, gy], 1) + rng.uniform(-jitter, jitter, (nx * ny, 2)) if jitter > 0 else 0.0
+    xy = np.array([1.7, 6.5]) + 0.075 * np.stack([gx, gy], 1) + (rng.uniform(-jitter, jitter, (nx * ny, 2)) if jitter > 0 else 0.0)
     uv = np.zeros((nx * ny, 2))
     for lo, hi in ((30, 54), (114, 138)):      # the middle of either slab, well inside vertically
         cand = np.nonzero((gx >= lo) & (gx < hi) & (gy >= 10) & (gy < 30))[0]
