@@ -601,6 +601,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     ALLOC(a.bpos, nb); ALLOC(a.bvel, nb); ALLOC(a.bpsi, nb); ALLOC(a.bid, nb);
     ALLOC(a.grav, 1); ALLOC(a.flags, FLAG_WORDS); ALLOC(a.dn, 4); ALLOC(a.dyn, DYN_COUNT);
     ALLOC(a.gbar, (size_t)GBAR_WORDS * GBAR_STRIDE);
+    ALLOC(a.wcast, (size_t)WCAST_COPIES * GBAR_STRIDE);
     ALLOC(ctx->d_aos, n); ALLOC(ctx->d_baos, nb); ALLOC(ctx->d_du, n); ALLOC(ctx->d_dv, n); ALLOC(ctx->d_bits, 1024);
     ALLOC(ctx->d_ids, n);
     float2 *&bpos_in = ctx->d_bpos_in, *&bvel_in = ctx->d_bvel_in;
@@ -633,6 +634,7 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     HIPCHK(ctx, hipMemsetAsync(a.block_sums, 0, tiles * SCAN_SPREAD * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.flags, 0, FLAG_WORDS * sizeof(uint32_t), st));
     HIPCHK(ctx, hipMemsetAsync(a.gbar, 0, sizeof(uint32_t) * (size_t)GBAR_WORDS * GBAR_STRIDE, st));
+    HIPCHK(ctx, hipMemsetAsync(a.wcast, 0, sizeof(uint32_t) * (size_t)WCAST_COPIES * GBAR_STRIDE, st));
     a.rebuild = a.flags + FLAG_REBUILD;
     a.check = a.flags + FLAG_CHECK;
     a.latch = a.flags + FLAG_LATCH;
@@ -1233,7 +1235,13 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
 // ---- box calibration (sph_diag.h) ----
 namespace {
 __global__ __launch_bounds__(256) void k_cal_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {      // four loads in flight per thread
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 constexpr int CAL_ITERS = 4096, CAL_BLOCKS = 2048;
 __global__ __launch_bounds__(256) void k_cal_valu(float *out, float seed, unsigned long long *clocks) {

@@ -126,6 +126,9 @@ struct Arrays {
     float2 *grav;       // gravity vector read by the force kernel
     uint32_t *flags;    // see FLAG_*
     uint32_t *gbar;     // k_rebuild's grid barrier: GBAR_WORDS words, GBAR_STRIDE apart (arrivals, one per XCD, releases)
+    uint32_t *wcast;    // the speculative slab step: WCAST_COPIES copies (GBAR_STRIDE words apart) of "step << 2 | reduced rebuild word", written by
+                        // workgroup 0 of k_rebuild_slab, polled by the others — a few pollers per word (1 535 waves reading ONE word past their
+                        // L2s are served one after the other: ~36 us per step, measured)
     float4 *wbox;       // per box group (BOXG consecutive lanes of a tile: a wave): bounding box of displacement since the last rebuild
     uint32_t *wnbr;     // per group: WNBR_WORDS words = 6 x {first, last} group whose particles may come near this group's
     uint32_t *latch;    // slab mode: copy of the reduced rebuild word of the current step (flags + FLAG_LATCH)
@@ -185,7 +188,6 @@ enum {
     FLAG_STEP_DONE = 39,    // slab contexts: FLAG_STEP as the last k_rebuild_slab found it = the step that launch belonged to.  Nobody writes it
                             //   while a head kernel runs, so every block of k_slab_head can derive ITS step (this + 1) from the device alone:
                             //   what lets 2^k lean steps be captured as one graph (sph_slab_steps)
-    FLAG_WORD_READY = 44,   // the speculative slab step (k_rebuild_slab, spec): the step whose reduced rebuild word workgroup 0 has published (grows)
     FLAG_PEER_DIAG = 40,    // + 0..3: the first peer wait that gave up: site (1 k_peer_reduce, 2 k_peer_wait, 3 head: rebuild word, 4 lean: update, 5 lean: records)
                             //   << 8 | side or rank, the tag it waited for, the word it saw last, this rank's step count
     FLAG_WORDS = 64
@@ -244,6 +246,7 @@ constexpr int HALO_REC = 5;     // words per halo record
 enum { HALO_UPD_COUNT = 0, HALO_UPD_STEP = 1, HALO_REC_COUNT = 2, HALO_REC_STEP = 3 };
 
 constexpr int GBAR_MAX_WGS = 2048, GBAR_COPIES = 32, GBAR_STRIDE = 32;      // (words: 128 bytes apart)
+constexpr int WCAST_COPIES = 64;
 constexpr int GBAR_WORDS = GBAR_MAX_WGS + 8 + 8 * GBAR_COPIES + 8;      // arrivals, written back (per XCD), go (per XCD, in copies), leaders' XCDs
 constexpr int SCAN_ITEMS = 8;            // items per thread in the scan kernels
 constexpr int SCAN_BLOCK = 256;

@@ -372,19 +372,21 @@ def test_c_host_rebalancing_keeps_a_migrating_flow_inside_capacity(sph, tmp_path
 
 
 @pytest.mark.gpu
-def test_c_host_graphed_lean_steps_equal_single_calls_bitwise(sph, tmp_path):
+@pytest.mark.parametrize("spec", [0, 1])
+def test_c_host_graphed_lean_steps_equal_single_calls_bitwise(sph, tmp_path, spec):
     """sph_slab_steps (round 6): runs of 16 / 8 / 4 / 2 lean steps replayed as captured graphs — step number, buffer parity and gravity
     taken from device memory — against sph_slab_step, one call of four launches per step: three ranks over the peer transport on one
     GPU, the adaptive skin (most steps carry updates, some rebuild), the tilt trace (gravity changes between runs of steps),
-    deterministic order: the same rebuild steps and the same bits.  1 + 163 + 120 steps: runs that are no multiple of anything."""
+    deterministic order: the same rebuild steps and the same bits.  1 + 163 + 120 steps: runs that are no multiple of anything.
+    spec = 1: the speculative lean step (sph_slab_set_speculative) the same way."""
     states = []
     for graph in (1, 0):
         state = tmp_path / ("state_g%d.bin" % graph)
-        r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--lean-graph", graph, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
+        r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--lean-graph", graph, "--lean-spec", spec, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
                                  "--velocity", 5, 0, "--steps", 163, "--warmup", 121, "--tilt", "--deterministic", "--dump-state", state])
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200
-        assert ("graphs of up to 16 steps" in rec["host"]) == bool(graph)
+        assert ("graphs of up to 16 steps" in rec["host"]) == bool(graph) and ("speculative" in rec["host"]) == bool(spec)
         states.append((np.fromfile(state, sph.PARTICLE), rec["neighbour_rebuilds"]))
     assert states[0][1] == states[1][1]
     for k in ("x", "y", "u", "v", "rho", "p"):
@@ -392,15 +394,17 @@ def test_c_host_graphed_lean_steps_equal_single_calls_bitwise(sph, tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_host_lean_step_state_and_last_step_vs_oracle(sph, orc, oracle, tmp_path):
+@pytest.mark.parametrize("spec", [0, 1])
+def test_c_host_lean_step_state_and_last_step_vs_oracle(sph, orc, oracle, tmp_path, spec):
     """The lean step against the ORACLE (round 5's tests of it were bitwise against sph_step / the three-call step: transitive).  Two
     ranks over the peer transport, graphed runs of steps, the block flying through the interface at 5 m/s with the default (adaptive)
     skin: the C host dumps the gathered state and accelerations in front of the last step and behind it, and ONE oracle step from the
     former must give the latter (conftest.fused_step_vs_oracle: x, v_half, rho, p, a, v and the acceleration the kick used: all
-    within 1e-5 on their scales) — the integration of a slab step, the ghosts' densities included, pinned to pi_sph_fluid.c:612-641."""
+    within 1e-5 on their scales) — the integration of a slab step, the ghosts' densities included, pinned to pi_sph_fluid.c:612-641.
+    spec = 1: the speculative lean step (the criterion inside the density launch, the word exchanged by the gate kernel)."""
     from conftest import fused_step_vs_oracle
     fn = {k: tmp_path / (k + ".bin") for k in ("s0", "a0", "s1", "a1")}
-    r, out, rec = _run_host(["--ranks", 2, "--transport", "peer", "--lean", 1, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20, "--velocity", 5, 0,
+    r, out, rec = _run_host(["--ranks", 2, "--transport", "peer", "--lean", 1, "--lean-spec", spec, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20, "--velocity", 5, 0,
                              "--steps", 150, "--warmup", 50, "--dump-before", fn["s0"], fn["a0"], "--dump-state", fn["s1"], "--dump-accel", fn["a1"]])
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200 and "graphs of up to 16 steps" in rec["host"]
@@ -415,3 +419,31 @@ def test_c_host_lean_step_state_and_last_step_vs_oracle(sph, orc, oracle, tmp_pa
     worst = fused_step_vs_oracle(orc, oracle, p, ob, before, (a0[:, 0].copy(), a0[:, 1].copy()), after, (a1[:, 0].copy(), a1[:, 1].copy()),
                                  (0.0, -9.81), float(np.float32(prm.dt)), tag="lean step, 2 ranks, peer")
     assert max(worst.values()) <= 1.0, worst
+
+
+@pytest.mark.gpu
+def test_c_host_speculative_lean_step(sph, tmp_path):
+    """The speculative lean step (round 6, sph_slab_set_speculative; --lean-spec 1): one rank against sph_step (--check) — and what it
+    is for: on the dam break a slab through the plain lean step rebuilds its neighbour structure more than twice as often as sph_step
+    (failing boxes ask for the rebuild: the verification would sit on the step's critical path), through the speculative one about as
+    often as sph_step (the verification rides in the density launch).  Three ranks over the peer transport with re-balancing: every
+    particle owned once."""
+    r = subprocess.run([HOST, "--ranks", "1", "--block", "600", "150", "90", "20", "--steps", "150", "--warmup", "50", "--check", "--lean-spec", "1"],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = r.stdout.decode().splitlines()
+    rec = json.loads([ln for ln in out if ln.startswith("{")][0])
+    assert rec["particles_conserved"] is True and "speculative" in rec["host"]
+    chk = [ln for ln in out if ln.startswith("check:")]
+    assert len(chk) == 1 and chk[0].endswith("-> ok"), chk
+    rebuilds = {}
+    for spec in (1, 0):
+        r, out, rec = _run_host(["--ranks", 1, "--scene", "dam", "--steps", 400, "--warmup", 1200, "--lean-spec", spec, "--verify", 1 if spec else -1])
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert rec["particles_conserved"] is True
+        rebuilds[spec] = rec["neighbour_rebuilds"]
+    assert rebuilds[1] < 0.7 * rebuilds[0], rebuilds
+    r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--lean-spec", 1, "--one-launch-wgs", 256, "--block", 160, 40, 60, 6,
+                             "--origin", 2.0, 1.5, "--velocity", 30, 0, "--capacity", 3200, "--warmup", 0, "--steps", 900, "--rebalance-every", 150])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert rec["particles_conserved"] is True and rec["rebalanced"] >= 3 and "speculative" in rec["host"]

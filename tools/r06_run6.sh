@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 6, GPU call 6: the speculative lean step with the word fanned out
+cd "$(dirname "$0")/.." && . tools/gpu_steps.sh
+H=pi-sph-fluid_amd/host/slab_sph_fluid
+step 200 gpurun_out/r06_spec_check.txt $H --ranks 1 --block 600 150 90 20 --steps 150 --warmup 50 --check --lean-spec 1
+step 200 gpurun_out/r06_spec_check_ng.txt $H --ranks 1 --block 600 150 90 20 --steps 150 --warmup 50 --check --lean-spec 1 --lean-graph 0
+for sp in 1 0 1 0; do
+step 120 gpurun_out/r06_spec_2M_$sp.json $H --ranks 1 --scene dam --steps 1000 --warmup 200 --windows 5 --lean-spec $sp
+done
+for sp in 1 0; do
+step 200 gpurun_out/r06_spec_4Mdev_$sp.json $H --ranks 1 --scene cfg4slab --tilt --steps 200 --warmup 2000 --windows 3 --lean-spec $sp
+step 200 gpurun_out/r06_spec_4Mrest_$sp.json $H --ranks 1 --scene cfg4slab --tilt --steps 200 --warmup 50 --windows 3 --lean-spec $sp
+done
+step 900 gpurun_out/r06_t_slab_c2.log python -m pytest tests/test_slab_c_host.py -x -q -m gpu
+step 300 gpurun_out/r06_slab_repair_explore2.txt python tools/slab_repair_explore.py
