@@ -58,8 +58,9 @@ def main():
     worst = np.array([max(ln) for ln in rows])
     second = np.array([sorted(ln)[-2] for ln in rows])
     out = {"runs": runs, "ulps": ulps, "lines_per_run": len(rows[0]),
-           "worst_line_of_a_run_pct": {"min": float(worst.min()), "median": float(np.median(worst)), "max": float(worst.max()),
-                                       "runs_over_1pct": int((worst > 1.0).sum())},
+           "worst_line_of_a_run_pct": {"min": float(worst.min()), "median": float(np.median(worst)), "p75": float(np.percentile(worst, 75)),
+                                       "p90": float(np.percentile(worst, 90)), "p99": float(np.percentile(worst, 99)), "max": float(worst.max()),
+                                       "runs_over_1pct": int((worst > 1.0).sum()), "runs_over_0.6pct": int((worst > 0.6).sum())},
            "second_worst_line_pct": {"median": float(np.median(second)), "max": float(second.max())}}
     print(json.dumps(out))
 

@@ -343,21 +343,29 @@ def test_slab_metaballs_and_stats(sph, orc):
 def test_slabs_repair_their_lists(sph, orc):
     """List repair on slab contexts (round 5): the verification blocks of the slab step's head kernel append a pair that is inside the
     support and in nobody's list to the two lists, for groups whose neighbourhood holds owned particles only; the density pass of the
-    same step follows the head kernel and reads the repaired lists.  The jittered lattice with one particle in five at up to 40 m/s
-    (tests/test_gpu_verlet.py), wider, cut into two slabs, with verification and repairs switched on: no more rebuilds than without
-    them, and the run stays the single context's (12 steps: summation order only).  Verification alone: 7 -> 5 rebuilds here."""
+    same step follows the head kernel and reads the repaired lists.
+    Round 6 — the scene is one in which a slab MUST repair (round 5's jittered lattice relaxed everywhere, the groups next to the ghosts
+    asked for a rebuild every second step, and the assertion could only say `done >= 0`; tools/slab_repair_explore.py): a QUIET lattice
+    (jitter 2 mm: lists live for tens of steps) cut into two slabs, twelve particles deep inside either slab at 20 m/s.  They cross the
+    skin after ~7 steps and the drift cap after ~16: in between the verification finds pairs that are in nobody's list — with repairs on
+    both slabs append them (28 pairs each by step 32 on the exploration's box) and rebuild no more often than without; with repairs off
+    none are appended and those pairs ask for rebuilds.  After 12 steps the run is still the single context's (summation order only)."""
     import ctypes as C
     L = sph.hip_lib()
+    L.sph_repair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    L.sph_rebuild_reasons.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     rng = np.random.default_rng(11)
     box = (0.0, 16.0, 0.0, 16.0)
     prm = sph.default_params(box)
     nx, ny = 168, 40      # (wide: 50 cell columns — a slab's groups verify only where their neighbourhood holds no ghost slot)
     gx, gy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
-    xy = np.array([1.7, 6.5]) + 0.075 * np.stack([gx.ravel(), gy.ravel()], 1) + rng.uniform(-0.02, 0.02, (nx * ny, 2))
-    # (the fast ones in the middle third of either slab only: a group whose neighbourhood touches ghost slots keeps the absolute
-    # criterion — anybody beyond skin/2 there, and the slabs rebuild every other step whatever the verification says)
-    inner = ((gx.ravel() >= 24) & (gx.ravel() < 60)) | ((gx.ravel() >= 108) & (gx.ravel() < 144))
-    uv = rng.uniform(-40.0, 40.0, (nx * ny, 2)) * ((rng.random(nx * ny) < 0.2) & inner)[:, None]
+    gx, gy = gx.ravel(), gy.ravel()
+    xy = np.array([1.7, 6.5]) + 0.075 * np.stack([gx, gy], 1) + rng.uniform(-0.002, 0.002, (nx * ny, 2))
+    uv = np.zeros((nx * ny, 2))
+    for lo, hi in ((30, 54), (114, 138)):      # the middle of either slab, well inside vertically
+        pick = rng.choice(np.nonzero((gx >= lo) & (gx < hi) & (gy >= 10) & (gy < 30))[0], 12, replace=False)
+        ang = rng.uniform(0, 2 * np.pi, 12)
+        uv[pick] = 20.0 * np.stack([np.cos(ang), np.sin(ang)], 1)
     state = np.concatenate([xy, uv], 1).astype(np.float32)
     f = particles(orc, state, np.float32(prm.rho0) * np.float32(prm.vol))
     _p, _f, walls = sph.scene_disc(box, 8.0, 8.0, 0.1)
@@ -368,7 +376,7 @@ def test_slabs_repair_their_lists(sph, orc):
         ctx.step(12, 0.0, 0.0)
         ctx.sync()
         ref = ctx.read_particles()
-    rebuilds = {}
+    rebuilds, done, missing = {}, {}, {}
     for repair in (1, 0):
         parts = sph.slab.partition_columns(prm, f, 2, slack=8)
         slabs = [sph.slab.GpuSlab(sph, prm, f, walls, c0, c1, r > 0, r < 1, 0.0, 0.0) for r, (c0, c1) in enumerate(parts)]
@@ -380,21 +388,23 @@ def test_slabs_repair_their_lists(sph, orc):
             s_.sync()
         out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
         assert np.all(seen == 1)
-        # (12 steps: the runs differ by summation order and by the steps in which they rebuild; by 30 steps collisions at 80 m/s have
-        # amplified that to 1e-4 m between ANY two of them — the single context with and without repairs included)
         assert max(np.abs(out["x"] - ref["x"]).max(), np.abs(out["y"] - ref["y"]).max()) <= 2e-5, repair
         assert np.max(np.abs(out["rho"] - ref["rho"]) / ref["rho"]) <= 1e-4, repair
-        done = 0
+        runner.step(20, 0.0, 0.0)      # ... on to step 32: past the skin, up to the drift cap
         for s_ in slabs:
-            a = (C.c_longlong * 4)()
-            L.sph_repair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-            assert L.sph_repair_stats(s_.h, a) == 0
-            done += a[0]
-        # (whether a pair goes missing before these slabs rebuild anyway — box pairs the verification cannot take, every other step at
-        # these speeds — is the flow's business: the repair path is the single context's, minus its queue; without it, none)
-        assert done >= 0 and (repair or done == 0), (repair, done)
+            s_.sync()
+        done[repair], missing[repair] = [], 0
+        for s_ in slabs:
+            a, w = (C.c_longlong * 4)(), (C.c_longlong * 4)()
+            assert L.sph_repair_stats(s_.h, a) == 0 and L.sph_rebuild_reasons(s_.h, w) == 0
+            done[repair].append(int(a[0]))
+            missing[repair] += int(w[1])      # requests "the verification found a pair missing from the lists"
         rebuilds[repair] = slabs[0].rebuilds()
+        out, du, dv, seen = runner.gather_local(len(f), sph.PARTICLE)
+        assert np.all(seen == 1) and np.all(np.isfinite(out["x"])) and np.all(np.isfinite(out["rho"]))
         for s_ in slabs:
             s_.close()
+    assert all(d > 0 for d in done[1]), done            # EVERY slab repaired lists ...
+    assert all(d == 0 for d in done[0]) and missing[0] > 0, (done, missing)      # ... that, without repairs, asked for rebuilds
     # (switching the repair on asks for ONE rebuild: lists built while it was off have neither the spare row nor the remembered partners)
     assert rebuilds[1] <= rebuilds[0] + 1, rebuilds

@@ -194,21 +194,22 @@ def test_c_host_lean_step_over_peer_mapped_memory_equals_sph_step_bitwise(sph, t
     records pushed into the neighbours' mapped receive buffers and theirs awaited between two of its grid barriers, the rebuild
     word exchanged by the head kernel.  Bit for bit sph_step's particles after 300 steps of a block flying through the
     interfaces."""
-    state = tmp_path / "state.bin"
-    r, out, rec = _run_host(["--ranks", ranks, "--transport", "peer", "--lean", 1, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
-                             "--velocity", 5, 0, "--steps", 250, "--warmup", 50, "--deterministic", "--skin", 0, "--dump-state", state])
-    assert r.returncode == 0, r.stderr.decode()[-3000:]
-    assert rec["n_gpus"] == ranks and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True and rec["neighbour_rebuilds"] >= 300
-    assert "peer-mapped" in rec["host"] and "lean step" in rec["host"]
-    got = np.fromfile(state, sph.PARTICLE)
     prm, f, b = _flying_block(sph)
     with sph.Context(prm, f, b, 0.0, -9.81) as ctx:
         ctx.step(300, 0.0, -9.81)
         ctx.sync()
         ref = ctx.read_particles()
-    assert len(got) == len(ref)
-    for k in ("x", "y", "u", "v", "rho", "p"):
-        assert np.array_equal(got[k], ref[k]), k
+    for spec in (1, 0):      # (round 6: the speculative lean step, the C host's default — the word goes round in the gate kernel — and the plain one)
+        state = tmp_path / ("state%d.bin" % spec)
+        r, out, rec = _run_host(["--ranks", ranks, "--transport", "peer", "--lean", 1, "--lean-spec", spec, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
+                                 "--velocity", 5, 0, "--steps", 250, "--warmup", 50, "--deterministic", "--skin", 0, "--dump-state", state])
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        assert rec["n_gpus"] == ranks and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True and rec["neighbour_rebuilds"] >= 300
+        assert "peer-mapped" in rec["host"] and "lean step" in rec["host"] and ("speculative" in rec["host"]) == bool(spec)
+        got = np.fromfile(state, sph.PARTICLE)
+        assert len(got) == len(ref)
+        for k in ("x", "y", "u", "v", "rho", "p"):
+            assert np.array_equal(got[k], ref[k]), (k, spec)
 
 
 @pytest.mark.gpu
@@ -223,7 +224,7 @@ def test_c_host_lean_step_updates_equal_the_three_call_step_bitwise(sph, tmp_pat
         states = []
         for lean in (1, 0):
             state = tmp_path / ("state%d%d.bin" % (lean, verify))
-            r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", lean, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
+            r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", lean, "--lean-spec", 0, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
                                      "--velocity", 5, 0, "--steps", 300, "--warmup", 100, "--deterministic", "--verify", verify, "--dump-state", state])
             assert r.returncode == 0, r.stderr.decode()[-3000:]
             assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200 and ("lean step" in rec["host"]) == bool(lean)
@@ -236,7 +237,7 @@ def test_c_host_lean_step_updates_equal_the_three_call_step_bitwise(sph, tmp_pat
     # re-balancing under the lean step: the block of test_c_host_rebalancing_..., flying along x at 30 m/s out of the first slab and
     # into the last — the contexts are re-created (their step counts, the tags of the lean step's messages, start from 1 again:
     # the flags and word slots of the peer blocks with them)
-    r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--one-launch-wgs", 256, "--block", 160, 40, 60, 6,
+    r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--lean-spec", 0, "--one-launch-wgs", 256, "--block", 160, 40, 60, 6,
                              "--origin", 2.0, 1.5, "--velocity", 30, 0, "--capacity", 3200, "--warmup", 0, "--steps", 900, "--rebalance-every", 150])
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert rec["particles_conserved"] is True and rec["rebalanced"] >= 3 and "lean step" in rec["host"]
