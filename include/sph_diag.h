@@ -52,7 +52,8 @@ int  sph_profile_steps(sph_ctx *ctx, float gx, float gy, int nsteps, sph_kernel_
  * SPH_K_FORCE_KICK re-does the kick of the last step: valid only after at least one sph_step since creation / upload /
  * sph_eval_accel — SPH_E_STATE otherwise: the velocities would be kicked a second time.  SPH_K_BUILD_LIST (single-GPU
  * contexts) rebuilds the lists on the sort that is there and leaves the rebuild request raised, so the next step
- * redoes the whole neighbour structure. */
+ * redoes the whole neighbour structure.  SPH_K_DENSITY_SPEC: for the duration of the measurement the criterion's jobs are told not to
+ * repair lists (a pair they find missing only raises the rebuild word, which is put back): the state is left as it was found. */
 int  sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms);
 /* select kernel variant for density/force: 0 = default (best), others for A/B measurements */
 int  sph_set_variant(sph_ctx *ctx, int variant);

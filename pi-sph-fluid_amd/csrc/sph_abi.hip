@@ -382,7 +382,7 @@ int resort_state(sph_ctx *ctx) {
 
 // what the rebuild-criterion jobs read (SpecJobs, sph_internal.h), one record per orientation of the two position / velocity sets:
 // at creation, and again when a slab adopts a rebuild word of its host's
-int upload_jobs(sph_ctx *ctx) {
+int upload_jobs(sph_ctx *ctx, bool no_repair = false) {      // no_repair: sph_time_kernel's launches must not change the lists
     Arrays &a = ctx->a;
     if (!a.djobs[0]) return SPH_OK;
     float2 *const first = a.pos_first, *const other = a.pos == a.pos_first ? a.pos2 : a.pos;
@@ -395,7 +395,7 @@ int upload_jobs(sph_ctx *ctx) {
     // collapse (steps 1200-2200, repairs in nearly every step) 8 660 -> 7 940, its other windows unchanged.
     // Slab contexts repair too (the verification blocks of their head kernel, k_slab_head): their density pass runs after the head
     // kernel, on the repaired lists — there is nothing to repeat and no queue.
-    const bool repair = list_repair(ctx);
+    const bool repair = list_repair(ctx) && !no_repair;
     const bool queued = !ctx->slab || ctx->lean_spec;      // (the density pass runs beside the repairs: their tiles are queued for a repeat)
     uint32_t *rq = repair && queued ? a.rq : nullptr;
     const uint32_t repair_kind = !repair ? 0u : queued ? 1u : 2u;
@@ -1209,6 +1209,10 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     // the speculative launch as the step issues it (its criterion jobs read the boxes the last force pass left: whatever they find,
     // the words they raise are put back after every launch, where the step's gate would clear them or rebuild)
     const bool verify = ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0;
+    // (the verify jobs of the timed launches must not repair lists — appended entries, FLAG_NREPAIR, xpair would outlive the measurement:
+    // for its duration the jobs' record says "no repairs"; a missing pair then only raises the word, which is put back)
+    const bool mute_repair = kernel == SPH_K_DENSITY_SPEC && list_repair(ctx);
+    if (mute_repair) { int rc = upload_jobs(ctx, true); if (rc) return rc; }
     if (kernel == SPH_K_DENSITY_SPEC) launch_spec_reset(ctx->stream, ctx->a, 0);
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int r = 0; r < reps; r++) {
@@ -1228,6 +1232,7 @@ int sph_time_kernel(sph_ctx *ctx, int kernel, int reps, float *ms) {
     float t = 0;
     HIPCHK(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
     *ms = t / reps;
+    if (mute_repair) { int rc = upload_jobs(ctx); if (rc) return rc; }
     HIPCHK(ctx, hipGetLastError());
     return SPH_OK;
 }
