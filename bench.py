@@ -64,6 +64,8 @@ def box_calibration(sph):
     """What THIS box delivers (sph_box_calibrate, include/sph_diag.h): 3 x ~50 ms of a streaming copy over 1 GiB and of a saturated
     v_fma_f32 stream, medians.  The boxes of the pool differ by +-5-8 % for one build of the library; with this record a figure can be
     normalised for its box (`*_vs_copy`: fractions of the MEASURED copy bandwidth instead of the 8 TB/s specification)."""
+    if os.environ.get("SPH_BENCH_BOX", "1") == "0":      # (profiles/collect.sh: the calibration kernels would fill the kernel trace)
+        return {"status": "skipped ($SPH_BENCH_BOX=0)"}
     try:
         b = sph.box_calibrate(0, 3)
         b["what"] = ("copy_gbs: read + write bytes / time of a float4 copy kernel over 1 GiB; valu_cycles: SIMD-cycles per wave-instruction "

@@ -17,6 +17,7 @@ root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out/prof_$tag"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
+export SPH_BENCH_BOX=0      # (bench.py's box calibration — ~100 ms of copy and v_fma kernels — stays out of the traces)
 B="python3 $root/bench.py --no-cpu --no-also $*"
 W="${SPH_PROF_WARM:-100}"; S="${SPH_PROF_STEPS:-300}"; PW="${SPH_PROF_PMC_WARM:-30}"
 R=""; [ -n "${SPH_PROF_PMC_RANGE:-}" ] && R="--kernel-iteration-range ${SPH_PROF_PMC_RANGE}"
