@@ -343,6 +343,10 @@ int  sph_slab_steps(sph_ctx *ctx, const float *gravity_xy, int nsteps);
  *     gate      the MAX of the rebuild word over the ranks (by its first workgroup; the others wait for it), then nothing — or the
  *               rebuild of the plain lean step AND the density pass again on the new lists
  *     force     as before
+ * on = 2: the FUSED form — the head's work (books, push, wait, ghost update) by the first workgroups of the density launch itself; tiles
+ * that stage ghost particles wait for them, every other tile starts at once: THREE launches per step, as sph_step, and the exchange of
+ * the update message hides behind the interior tiles.  Step number, buffer parity and gravity then always come from device memory (the
+ * gravity through a ring of 16 samples that sph_slab_step / sph_slab_steps keep fed).
  * Every rank of a run must use the same setting (the word is exchanged by different kernels). */
 int  sph_slab_set_speculative(sph_ctx *ctx, int on);
 /* bytes of one halo buffer of a slab created with these parameters and this halo_capacity (0 = default): what a host

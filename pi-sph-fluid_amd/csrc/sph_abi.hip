@@ -42,7 +42,13 @@ struct sph_ctx {
     bool gseq_valid = false, gseq_used[8] = {};
     hipEvent_t gseq_ev[8] = {};
     unsigned gseq_slot = 0;
-    bool lean_spec = false;      // sph_slab_set_speculative: the lean step with the criterion inside the launch of a speculative density pass
+    int lean_spec = 0;           // sph_slab_set_speculative: 1 = the lean step with the criterion inside the launch of a speculative density pass;
+                                 // 2 = ... and the head kernel's work as the first workgroups of that launch (three launches per step)
+    SlabFuse *d_fuse = nullptr;  // mode 2: what those workgroups need (device record) and the gravity ring they read (2 x GRAV_RING floats)
+    float *d_gring = nullptr;
+    float h_gring[2 * GRAV_RING] = {};      // the ring as the device holds it (or will, in stream order)
+    bool gring_valid = false;
+    int fuse_blocks = 0;
     bool step_done_synced = true;   // FLAG_STEP_DONE == FLAG_STEP between steps (k_rebuild_slab keeps it; the per-phase kernels do not)
     bool own_halo = false;      // halo buffers allocated by the library (else adopted from the host framework)
     size_t halo_bytes = 0;
@@ -93,6 +99,7 @@ constexpr int MAX_DEVICES = 64;
 constexpr int GSEQ_SLOTS = 8;      // pinned staging slots of sph_slab_steps' gravity samples
 std::atomic<int> g_live_contexts[MAX_DEVICES];
 bool device_shared(const sph_ctx *ctx);
+int upload_fuse(sph_ctx *ctx);      // (the fused speculative slab step: defined with the lean step below)
 
 int fail(sph_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
     if (ctx) {
@@ -396,11 +403,11 @@ int upload_jobs(sph_ctx *ctx, bool no_repair = false) {      // no_repair: sph_t
     // Slab contexts repair too (the verification blocks of their head kernel, k_slab_head): their density pass runs after the head
     // kernel, on the repaired lists — there is nothing to repeat and no queue.
     const bool repair = list_repair(ctx) && !no_repair;
-    const bool queued = !ctx->slab || ctx->lean_spec;      // (the density pass runs beside the repairs: their tiles are queued for a repeat)
+    const bool queued = !ctx->slab || ctx->lean_spec != 0;      // (the density pass runs beside the repairs: their tiles are queued for a repeat)
     uint32_t *rq = repair && queued ? a.rq : nullptr;
     const uint32_t repair_kind = !repair ? 0u : queued ? 1u : 2u;
     const SpecJobs j0 = {a.wbox, a.wnbr, a.dyn, a.flags, a.vq, a.rebuild, a.check, a.dn, a.lrec, first, a.pos_ref, vfirst, a.uref,
-                         a.tiles, a.nlist, a.stab, a.xranges, rq, a.xpair, repair_kind};
+                         a.tiles, a.nlist, a.stab, a.xranges, rq, a.xpair, ctx->slab && ctx->lean_spec == 2 ? ctx->d_fuse : nullptr, repair_kind};
     SpecJobs j1 = j0;
     j1.pos = other;
     j1.vel = vother;
@@ -610,6 +617,8 @@ int init_context(sph_ctx *ctx, const sph_params *prm, const sph_particle *fluid,
     a.send[0] = a.send[1] = a.recv[0] = a.recv[1] = nullptr;
     if (slab) {
         ALLOC(ctx->d_gseq, 2 * MULTI_STEPS);
+        ALLOC(ctx->d_fuse, 1);
+        ALLOC(ctx->d_gring, 2 * GRAV_RING);
         HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_gseq), sizeof(float) * 2 * MULTI_STEPS * GSEQ_SLOTS, hipHostMallocDefault));
         for (auto &e : ctx->gseq_ev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->halo_bytes = sizeof(uint32_t) * (HALO_HDR + (size_t)HALO_REC * slab->halo_cap);
@@ -1445,6 +1454,11 @@ int sph_slab_set_peer_links(sph_ctx *ctx, const sph_peer_links *links) {
         return fail(ctx, SPH_E_ARG, "sph_slab_set_peer_links: a neighbour's buffers or flags are missing");
     ctx->links = *links;
     ctx->has_links = true;
+    if (ctx->lean_spec == 2) {
+        int rc = upload_fuse(ctx);
+        if (rc) return rc;
+        if (ctx->fuse_blocks > 508) { ctx->lean_spec = 1; return upload_jobs(ctx); }
+    }
     return SPH_OK;
 }
 
@@ -1503,6 +1517,49 @@ bool fill_peer(sph_ctx *ctx, uint32_t step, PeerHead &ph, PeerLinks &pl) {
     return true;
 }
 
+// mode 2: the record the head blocks of the fused density launch read (after the links or the mode have changed)
+int upload_fuse(sph_ctx *ctx) {
+    if (!ctx->slab || !ctx->d_fuse) return SPH_OK;
+    SlabFuse F = {};
+    PeerLinks pl;
+    const bool peer = fill_peer(ctx, 0u, F.ph, pl);
+    for (int par = 0; par < 2; par++) { F.recv_l[par] = pl.recv_l[par]; F.recv_r[par] = pl.recv_r[par]; }
+    F.my_flag_l = pl.my_flag_l;
+    F.my_flag_r = pl.my_flag_r;
+    F.send_l = ctx->a.send[0];
+    F.send_r = ctx->a.send[1];
+    F.grav = ctx->a.grav;
+    F.gring = ctx->d_gring;
+    ctx->fuse_blocks = slab_fuse_blocks(ctx->c, peer, &F.npush, &F.nupd);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_fuse, &F, sizeof F, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // (a local)
+    return SPH_OK;
+}
+
+// mode 2: the gravity of steps first .. first + n - 1 into the ring (the sample of step s at s mod GRAV_RING), uploaded when it differs from
+// what the device holds
+int feed_gravity_ring(sph_ctx *ctx, uint32_t first, const float *gravity_xy, int n) {
+    float want[2 * GRAV_RING];
+    memcpy(want, ctx->h_gring, sizeof want);
+    for (int k = 0; k < n; k++) {
+        const uint32_t at = (first + (uint32_t)k) % (uint32_t)GRAV_RING;
+        want[2 * at] = gravity_xy[2 * k];
+        want[2 * at + 1] = gravity_xy[2 * k + 1];
+    }
+    if (ctx->gring_valid && memcmp(want, ctx->h_gring, sizeof want) == 0) return SPH_OK;
+    const int slot = ctx->gseq_slot++ % GSEQ_SLOTS;
+    if (ctx->gseq_used[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->gseq_ev[slot]));
+    float *h = ctx->h_gseq + (size_t)slot * 2 * MULTI_STEPS;
+    static_assert(GRAV_RING <= MULTI_STEPS, "the pinned staging slots hold a whole ring");
+    memcpy(h, want, sizeof want);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_gring, h, sizeof want, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->gseq_ev[slot], ctx->stream));
+    ctx->gseq_used[slot] = true;
+    memcpy(ctx->h_gring, want, sizeof want);
+    ctx->gring_valid = true;
+    return SPH_OK;
+}
+
 // the four launches of one lean step; gravity: this step's (gx, gy) as launch arguments (one call per step), or gravity_dev: where the
 // head kernel finds them in device memory (a node of a graph)
 void enqueue_lean_step(sph_ctx *ctx, const float *gravity, const float *gravity_dev, uint32_t step, bool stall_hook) {
@@ -1510,6 +1567,18 @@ void enqueue_lean_step(sph_ctx *ctx, const float *gravity, const float *gravity_
     PeerHead ph;
     PeerLinks pl;
     const bool peer = fill_peer(ctx, step, ph, pl);
+    if (ctx->lean_spec == 2) {
+        // the FUSED speculative lean step: three launches, as sph_step — the head's work by the first workgroups of the density launch
+        // (everything per step from the device: SlabFuse), the gate, the force pass
+        launch_density(st, ctx->c, ctx->a, ctx->cap, DENS_RHO_EOS, ctx->variant, false, DENS_ALL, false, true,
+                       ctx->verify_mode < 0 ? ctx->n >= VERIFY_MIN_PARTICLES : ctx->verify_mode > 0, ctx->fuse_blocks > 0 ? ctx->fuse_blocks : 4);      // 1
+        Arrays ga = ctx->a;
+        if (!list_repair(ctx)) { ga.rq = nullptr; ga.xpair = nullptr; }
+        pl.step = 0u;
+        launch_rebuild_slab(st, ctx->c, ga, ctx->cap, ctx->rebuild_wgs, ctx->deterministic, peer ? 7 : 5, peer ? &pl : nullptr);       // 2
+        launch_force(st, ctx->c, ctx->a, ctx->cap, FORCE_KICK_DRIFT, ctx->variant);                                                    // 3
+        return;
+    }
     if (ctx->lean_spec) {
         // the speculative lean step: books + push + ghost update | density with the criterion's jobs in its launch (as sph_step) | the gate:
         // MAX of the word over the ranks, then nothing, or the rebuild and the density pass again | force
@@ -1569,12 +1638,17 @@ hipGraphExec_t lean_graph(sph_ctx *ctx, int steps) {
 }  // namespace
 
 int sph_slab_set_speculative(sph_ctx *ctx, int on) {
-    if (!ctx || !ctx->stream || !ctx->slab || on < 0 || on > 1) return SPH_E_ARG;
+    if (!ctx || !ctx->stream || !ctx->slab || on < 0 || on > 2) return SPH_E_ARG;
     if (ctx->slab_phase != 0) return fail(ctx, SPH_E_STATE, "sph_slab_set_speculative mid-step");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     drop_graph(ctx);
-    ctx->lean_spec = on != 0;
+    ctx->lean_spec = on;
+    if (on == 2) {
+        int rc = upload_fuse(ctx);
+        if (rc) return rc;
+        if (ctx->fuse_blocks > 508) ctx->lean_spec = 1;      // (more head blocks than the launch's last argument can say: the four-launch form)
+    }
     return upload_jobs(ctx);      // (repaired tiles are queued for a repeat of their density only where a density pass runs beside the repairs)
 }
 
@@ -1600,6 +1674,15 @@ int sph_slab_step(sph_ctx *ctx, float gx, float gy) {
         if (ctx->c.has_right) ctx->a.recv[1] = static_cast<uint32_t *>(ctx->links.my_recv_right[par]);
     }
     const float gravity[2] = {gx, gy};
+    if (ctx->lean_spec == 2) {      // (everything per step from the device: the step number from FLAG_STEP_DONE, the gravity from the ring)
+        rc = feed_gravity_ring(ctx, step, gravity, 1);
+        if (rc) return rc;
+        if (!ctx->step_done_synced) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->a.flags + FLAG_STEP_DONE, ctx->a.flags + FLAG_STEP, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            ctx->step_done_synced = true;
+        }
+        enqueue_lean_step(ctx, nullptr, nullptr, 0u, false);
+    } else
     enqueue_lean_step(ctx, gravity, nullptr, step, true);
     ctx->velt_stale = true;
     ctx->acc_stale = true;
@@ -1628,6 +1711,10 @@ int sph_slab_steps(sph_ctx *ctx, const float *gravity_xy, int nsteps) {
         }
         // this run's gravity samples -> device (skipped while they repeat what is there: a 10 Hz gravity source changes every ~400 steps)
         const float *gs = gravity_xy + 2 * s;
+        if (ctx->lean_spec == 2) {      // (the fused step reads the ring: the sample of step t at t mod GRAV_RING)
+            rc = feed_gravity_ring(ctx, ctx->lean_step + 1u, gs, m);
+            if (rc) return rc;
+        } else
         if (!ctx->gseq_valid || memcmp(ctx->h_gseq_last, gs, sizeof(float) * 2 * (size_t)m) != 0) {
             const int slot = ctx->gseq_slot++ % GSEQ_SLOTS;
             if (ctx->gseq_used[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->gseq_ev[slot]));      // (the copy that read this slot last has run)

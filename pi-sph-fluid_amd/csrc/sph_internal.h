@@ -59,6 +59,7 @@ struct Consts {
 // What the rebuild-criterion jobs inside the launch of the speculative density pass need (spec_check_job, spec_verify_job:
 // sph_list.inc).  In device memory behind ONE kernel argument: as a dozen arguments of their own these pointers were fetched
 // at the top of the kernel by every workgroup and their scalar registers lived across the whole walk of the tiles' waves.
+struct SlabFuse;
 struct SpecJobs {
     const float4 *wbox;
     const uint32_t *wnbr;
@@ -80,6 +81,7 @@ struct SpecJobs {
     uint2 *xpair;           // per tile lane (like lrec): up to two partners (sorted indices) of pairs this lane's particle was repaired
                             // with since the last rebuild (0xffffffff: none) — how the verification of the following steps knows, from one
                             // coalesced load, the pairs it has dealt with (they break its rule "listed exactly if within the cut-off then")
+    const struct SlabFuse *fuse;   // the fused speculative slab step (sph_slab_set_speculative(ctx, 2)): what the head blocks of the density launch need; else null
     uint32_t repair;        // 0: a missing pair asks for the rebuild; 1: list repair, repaired tiles queued in rq (single-GPU contexts: the
                             // speculative density pass of the same launch may have read the lists as they were); 2: list repair, no queue
 };
@@ -188,6 +190,8 @@ enum {
     FLAG_STEP_DONE = 39,    // slab contexts: FLAG_STEP as the last k_rebuild_slab found it = the step that launch belonged to.  Nobody writes it
                             //   while a head kernel runs, so every block of k_slab_head can derive ITS step (this + 1) from the device alone:
                             //   what lets 2^k lean steps be captured as one graph (sph_slab_steps)
+    FLAG_GHOSTS_READY = 45, // the fused speculative slab step: the step whose ghost update the update blocks of the density launch have completed (grows)
+    FLAG_UPD_DONE = 46,     //   ... and their completion count (grows by the number of update blocks per launch)
     FLAG_PEER_DIAG = 40,    // + 0..3: the first peer wait that gave up: site (1 k_peer_reduce, 2 k_peer_wait, 3 head: rebuild word, 4 lean: update, 5 lean: records)
                             //   << 8 | side or rank, the tag it waited for, the word it saw last, this rank's step count
     FLAG_WORDS = 64
@@ -294,6 +298,21 @@ struct PeerLinks {     // k_rebuild_slab, lean: wait for the update | exchange t
     const uint32_t *my_slots;
     int me, nranks;
 };
+// Round 6, the FUSED speculative lean step (sph_slab_set_speculative(ctx, 2)): the head kernel's work — the books, the push of the update
+// message, the wait for the neighbours' and the ghost update — as the FIRST workgroups of the speculative density launch; tiles that stage
+// ghost particles (TileInfo::ghost, set by the list build) wait for FLAG_GHOSTS_READY, every other tile starts at once: three launches
+// per step, as sph_step, and the exchange of the update hides behind the interior tiles.  Everything per step comes from the device:
+// the step number (FLAG_STEP_DONE + 1), the parity of the buffers, the gravity (a ring of 16 samples: the sample of step s at s & 15).
+struct SlabFuse {
+    PeerHead ph;                                     // (step = 0: from the device)
+    uint32_t *recv_l[2], *recv_r[2];                 // this rank's own receive buffers by parity
+    const uint32_t *my_flag_l, *my_flag_r;           // this rank's own arrival flags
+    uint32_t *send_l, *send_r;
+    float2 *grav;                                    // where the force pass reads the step's gravity
+    const float *gring;                              // 2 x 16 floats
+    int npush, nupd;                                 // head blocks of the density launch: push, update (0: no neighbours)
+};
+constexpr int GRAV_RING = 16;
 // gravity: the step's (gx, gy) as launch arguments — or gravity_dev (device memory, two floats) when the launch is a node of a graph
 // spec: the head of the speculative lean step — no criterion blocks, no word exchange; with links it also waits for the neighbours' update
 // and updates the ghosts (links: the receive buffers and own flags)
@@ -353,8 +372,11 @@ enum { DENS_ALL = 0, DENS_INTERIOR = 1, DENS_REST = 2 };
 // evaluates the rebuild criterion of every box group on the way (what k_check + k_verify do as launches of their own); it
 // raises the rebuild word and clears nothing: launch_rebuild(..., spec = true) must follow.  verify (spec only): two boxes that
 // have moved more than the skin relative to each other are checked particle by particle; false: they ask for the rebuild.
+// head_blocks (spec, slab contexts in the fused speculative step): so many workgroups in front of everything else do the slab head's work
+// (a multiple of 4, at most 508; SpecJobs::fuse says what)
 void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild,
-                    int pass = DENS_ALL, bool store_p = true, bool spec = false, bool verify = true);
+                    int pass = DENS_ALL, bool store_p = true, bool spec = false, bool verify = true, int head_blocks = 0);
+int slab_fuse_blocks(const Consts &c, bool peers, int *npush, int *nupd);      // the head blocks a slab context's fused density launch needs
 // what the force pass writes besides a: nothing / velt (second half kick) / velt + the next step's kick 1/2 + drift
 // into pos2, vel2 + the next step's rebuild request
 enum { FORCE_EVAL = 0, FORCE_KICK = 1, FORCE_KICK_DRIFT = 2 };

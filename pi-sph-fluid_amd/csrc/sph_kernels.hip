@@ -1241,9 +1241,9 @@ void launch_peer_wait(hipStream_t st, const Arrays &a, const void *flag_l, const
 namespace sph {
 
 void launch_density(hipStream_t st, const Consts &c, const Arrays &a, int cap, int mode, int variant, bool consume_rebuild,
-                    int pass, bool store_p, bool spec, bool verify) {
+                    int pass, bool store_p, bool spec, bool verify, int head_blocks) {
     if (cap <= 0) return;
-    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild, pass, store_p, spec, verify); return; }
+    if (variant == 0) { launch_density_list(st, c, a, cap, mode, consume_rebuild, pass, store_p, spec, verify, head_blocks); return; }
     if (pass == DENS_INTERIOR) return;      // the direct variant is not split: everything in the final pass
     dim3 g((cap + BLK - 1) / BLK), b(BLK);
     uint32_t *rb = consume_rebuild ? a.rebuild : nullptr;

@@ -30,7 +30,7 @@
  *                  [--velocity U V] [--steps K] [--warmup W] [--windows N] [--tilt] [--check] [--deterministic] [--skin F]
  *                  [--rebalance-every K] [--capacity N] [--halo-capacity N] [--console] [--frame FILE] [--dump-state FILE] [--dump-accel FILE]
  *                  [--dump-before STATE_FILE ACCEL_FILE]      (the state and accelerations in front of the last step: tests pin ONE slab step to the oracle)
- *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--lean-graph 0|1] [--lean-spec 0|1] [--one-launch-wgs N] [--verify -1|0|1] [--repair -1|0|1]
+ *                  [--selfcomm] [--exchange-stream serial|main|side] [--breakdown K] [--lean auto|0|1] [--lean-graph 0|1] [--lean-spec 0|1|2] [--one-launch-wgs N] [--verify -1|0|1] [--repair -1|0|1]
  * starts N processes (fork + exec of this program with --rank r, before anything touches a GPU), rank r on device
  * r (rccl) or r mod devices (host).  --ranks 1 without --rank runs the one rank in this process: no fork, no exec (this is
  * what may sit under a profiler; the launcher must not: see profiles/README.md).  The ncclUniqueId travels through a file
@@ -558,7 +558,7 @@ static int make_context(rank_state *rs, int c0, int c1, const sph_particle *loc,
         if (desc.has_right) L.right_flag = (char *)rs->peer_of[me + 1] + peer_off_flag(rs, 0);
         SPHCHK(rs->ctx, sph_slab_set_peer_links(rs->ctx, &L));
     }
-    if (rs->lean && rs->lean_spec) SPHCHK(rs->ctx, sph_slab_set_speculative(rs->ctx, 1));
+    if (rs->lean && rs->lean_spec) SPHCHK(rs->ctx, sph_slab_set_speculative(rs->ctx, rs->lean_spec));
     SPHCHK(rs->ctx, sph_slab_flag_buffer(rs->ctx, &rs->flag));
     SPHCHK(rs->ctx, sph_slab_buffers(rs->ctx, &rs->x.send_l, &rs->x.send_r, &rs->x.recv_l, &rs->x.recv_r, &rs->x.halo_bytes));
     if (rs->transport == TR_PEER && rs->x.halo_bytes > rs->peer_halo) { fprintf(stderr, "[rank %d] halo buffers outgrew the peer block\n", rs->cm.rank); return 1; }
@@ -936,7 +936,7 @@ int main(int argc, char **argv) {
                         (nranks == 1 || transport == TR_PEER);
         rs.lean = lean_opt < 0 ? can : (lean_opt && can);
         rs.lean_graph = rs.lean && lean_graph_opt != 0;
-        rs.lean_spec = rs.lean && lean_spec_opt != 0;
+        rs.lean_spec = rs.lean ? (lean_spec_opt < 0 ? 0 : lean_spec_opt > 2 ? 2 : lean_spec_opt) : 0;
         if (lean_opt > 0 && !can) { fprintf(stderr, "[rank %d] --lean 1 needs --transport peer (or one rank) and the device to itself (or --one-launch-wgs)\n", rank); return 2; }
     }
     HIPCHK(hipSetDevice(rs.device));
@@ -1173,7 +1173,8 @@ rebalance_now:;
                "\"rank0_local\": %d, \"rank0_owned\": %d, \"rank0_density_ms\": %.5f, \"rank0_force_ms\": %.5f, \"particles_conserved\": %s, "
                "\"halo_buffer_bytes\": %zu, \"breakdown_steps\": %d, \"per_rank\": [",
                transport == TR_RCCL ? "RCCL" : transport == TR_PEER ? "peer-mapped memory" : "host-staged shared memory",
-               rs.lean ? (rs.lean_spec ? (rs.lean_graph ? ", lean step: 4 kernels, speculative, graphs of up to 16 steps" : ", lean step: 4 kernels, speculative")
+               rs.lean ? (rs.lean_spec == 2 ? (rs.lean_graph ? ", lean step: 3 kernels, speculative, head fused into the density launch, graphs of up to 16 steps" : ", lean step: 3 kernels, speculative, head fused into the density launch")
+                          : rs.lean_spec ? (rs.lean_graph ? ", lean step: 4 kernels, speculative, graphs of up to 16 steps" : ", lean step: 4 kernels, speculative")
                                        : (rs.lean_graph ? ", lean step: 4 kernels, graphs of up to 16 steps" : ", lean step: 4 kernels")) : "", sc.label, tilt ? ", scripted tilt gravity" : "", nranks, n_total, rs.nw,
                steps, warmup, n_win, tps, tps * (double)n_total / 1e6, steps > 0 ? elapsed / steps * 1e3 : 0.0, rebuilds, rebalanced, max_owned_ll, fm[0], fm[1],
                n_local, n_owned, dens_ms, force_ms, owned_total == (long long)n_total ? "true" : "false", rs.x.halo_bytes, bd_ok ? breakdown : 0);

@@ -199,13 +199,13 @@ def test_c_host_lean_step_over_peer_mapped_memory_equals_sph_step_bitwise(sph, t
         ctx.step(300, 0.0, -9.81)
         ctx.sync()
         ref = ctx.read_particles()
-    for spec in (1, 0):      # (round 6: the speculative lean step, the C host's default — the word goes round in the gate kernel — and the plain one)
+    for spec in (2, 1, 0):      # (round 6: the fused speculative lean step (3 launches), the speculative one (the word goes round in the gate kernel), the plain one)
         state = tmp_path / ("state%d.bin" % spec)
         r, out, rec = _run_host(["--ranks", ranks, "--transport", "peer", "--lean", 1, "--lean-spec", spec, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
                                  "--velocity", 5, 0, "--steps", 250, "--warmup", 50, "--deterministic", "--skin", 0, "--dump-state", state])
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         assert rec["n_gpus"] == ranks and rec["n_fluid"] == 90000 and rec["particles_conserved"] is True and rec["neighbour_rebuilds"] >= 300
-        assert "peer-mapped" in rec["host"] and "lean step" in rec["host"] and ("speculative" in rec["host"]) == bool(spec)
+        assert "peer-mapped" in rec["host"] and "lean step" in rec["host"] and ("speculative" in rec["host"]) == bool(spec) and ("fused" in rec["host"]) == (spec == 2)
         got = np.fromfile(state, sph.PARTICLE)
         assert len(got) == len(ref)
         for k in ("x", "y", "u", "v", "rho", "p"):
@@ -373,7 +373,7 @@ def test_c_host_rebalancing_keeps_a_migrating_flow_inside_capacity(sph, tmp_path
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spec", [0, 1])
+@pytest.mark.parametrize("spec", [0, 1, 2])
 def test_c_host_graphed_lean_steps_equal_single_calls_bitwise(sph, tmp_path, spec):
     """sph_slab_steps (round 6): runs of 16 / 8 / 4 / 2 lean steps replayed as captured graphs — step number, buffer parity and gravity
     taken from device memory — against sph_slab_step, one call of four launches per step: three ranks over the peer transport on one
@@ -395,14 +395,15 @@ def test_c_host_graphed_lean_steps_equal_single_calls_bitwise(sph, tmp_path, spe
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spec", [0, 1])
+@pytest.mark.parametrize("spec", [0, 1, 2])
 def test_c_host_lean_step_state_and_last_step_vs_oracle(sph, orc, oracle, tmp_path, spec):
     """The lean step against the ORACLE (round 5's tests of it were bitwise against sph_step / the three-call step: transitive).  Two
     ranks over the peer transport, graphed runs of steps, the block flying through the interface at 5 m/s with the default (adaptive)
     skin: the C host dumps the gathered state and accelerations in front of the last step and behind it, and ONE oracle step from the
     former must give the latter (conftest.fused_step_vs_oracle: x, v_half, rho, p, a, v and the acceleration the kick used: all
     within 1e-5 on their scales) — the integration of a slab step, the ghosts' densities included, pinned to pi_sph_fluid.c:612-641.
-    spec = 1: the speculative lean step (the criterion inside the density launch, the word exchanged by the gate kernel)."""
+    spec = 1: the speculative lean step (the criterion inside the density launch, the word exchanged by the gate kernel); 2: its fused
+    form (the head's work by the first workgroups of the density launch, ghost-staging tiles wait for them: three launches)."""
     from conftest import fused_step_vs_oracle
     fn = {k: tmp_path / (k + ".bin") for k in ("s0", "a0", "s1", "a1")}
     r, out, rec = _run_host(["--ranks", 2, "--transport", "peer", "--lean", 1, "--lean-spec", spec, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20, "--velocity", 5, 0,
@@ -429,22 +430,24 @@ def test_c_host_speculative_lean_step(sph, tmp_path):
     (failing boxes ask for the rebuild: the verification would sit on the step's critical path), through the speculative one about as
     often as sph_step (the verification rides in the density launch).  Three ranks over the peer transport with re-balancing: every
     particle owned once."""
-    r = subprocess.run([HOST, "--ranks", "1", "--block", "600", "150", "90", "20", "--steps", "150", "--warmup", "50", "--check", "--lean-spec", "1"],
-                       capture_output=True, timeout=600)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    out = r.stdout.decode().splitlines()
-    rec = json.loads([ln for ln in out if ln.startswith("{")][0])
-    assert rec["particles_conserved"] is True and "speculative" in rec["host"]
-    chk = [ln for ln in out if ln.startswith("check:")]
-    assert len(chk) == 1 and chk[0].endswith("-> ok"), chk
+    for mode in (1, 2):
+        r = subprocess.run([HOST, "--ranks", "1", "--block", "600", "150", "90", "20", "--steps", "150", "--warmup", "50", "--check", "--lean-spec", str(mode)],
+                           capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        out = r.stdout.decode().splitlines()
+        rec = json.loads([ln for ln in out if ln.startswith("{")][0])
+        assert rec["particles_conserved"] is True and "speculative" in rec["host"] and ("fused" in rec["host"]) == (mode == 2)
+        chk = [ln for ln in out if ln.startswith("check:")]
+        assert len(chk) == 1 and chk[0].endswith("-> ok"), chk
     rebuilds = {}
-    for spec in (1, 0):
+    for spec in (2, 1, 0):
         r, out, rec = _run_host(["--ranks", 1, "--scene", "dam", "--steps", 400, "--warmup", 1200, "--lean-spec", spec, "--verify", 1 if spec else -1])
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert rec["particles_conserved"] is True
         rebuilds[spec] = rec["neighbour_rebuilds"]
-    assert rebuilds[1] < 0.7 * rebuilds[0], rebuilds
-    r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--lean-spec", 1, "--one-launch-wgs", 256, "--block", 160, 40, 60, 6,
-                             "--origin", 2.0, 1.5, "--velocity", 30, 0, "--capacity", 3200, "--warmup", 0, "--steps", 900, "--rebalance-every", 150])
-    assert r.returncode == 0, r.stderr.decode()[-3000:]
-    assert rec["particles_conserved"] is True and rec["rebalanced"] >= 3 and "speculative" in rec["host"]
+    assert rebuilds[1] < 0.7 * rebuilds[0] and rebuilds[2] < 0.7 * rebuilds[0], rebuilds
+    for mode in (1, 2):
+        r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--lean-spec", mode, "--one-launch-wgs", 256, "--block", 160, 40, 60, 6,
+                                 "--origin", 2.0, 1.5, "--velocity", 30, 0, "--capacity", 3200, "--warmup", 0, "--steps", 900, "--rebalance-every", 150])
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        assert rec["particles_conserved"] is True and rec["rebalanced"] >= 3 and "speculative" in rec["host"]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: soak of the speculative lean step over the peer transport with several ranks on ONE GPU (time-sliced: launches of one rank are
-# held up for longer than a neighbour's whole step) — long runs, with and without graphs, re-balancing, the tilt trace, the stall hook
+# held up for longer than a neighbour's whole step) — long runs (re-balanced: the block flies 7 m, a static partition runs out of capacity), with and without graphs, re-balancing, the tilt trace, the stall hook
 cd "$(dirname "$0")/.." && . tools/gpu_steps.sh
 H=pi-sph-fluid_amd/host/slab_sph_fluid
 HS=pi-sph-fluid_amd/host/slab_sph_fluid_stress
@@ -8,7 +8,7 @@ B="--transport peer --lean 1 --one-launch-wgs 256 --block 600 150 90 20 --veloci
 n=0
 for ranks in 2 3 4; do for g in 1 0; do for sp in 1 0; do
   n=$((n+1))
-  step 200 gpurun_out/r06_soak_$n.txt $H --ranks $ranks $B --lean-graph $g --lean-spec $sp --steps 6000 --warmup 100 --tilt
+  step 200 gpurun_out/r06_soak_$n.txt $H --ranks $ranks $B --lean-graph $g --lean-spec $sp --steps 6000 --warmup 100 --tilt --rebalance-every 1000
   grep -o '"ticks_per_s": [0-9.]*\|"particles_conserved": [a-z]*\|"neighbour_rebuilds": [0-9]*' gpurun_out/r06_soak_$n.txt | tr '\n' ' '; echo " <- ranks $ranks graph $g spec $sp"
 done; done; done
 for rep in 1 2 3; do
