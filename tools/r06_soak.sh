@@ -6,14 +6,14 @@ H=pi-sph-fluid_amd/host/slab_sph_fluid
 HS=pi-sph-fluid_amd/host/slab_sph_fluid_stress
 B="--transport peer --lean 1 --one-launch-wgs 256 --block 600 150 90 20 --velocity 5 0"
 n=0
-for ranks in 2 3 4; do for g in 1 0; do for sp in 1 0; do
+for ranks in 2 3 4; do for g in 1 0; do for sp in ${SOAK_SPEC:-2 1 0}; do
   n=$((n+1))
   step 200 gpurun_out/r06_soak_$n.txt $H --ranks $ranks $B --lean-graph $g --lean-spec $sp --steps 6000 --warmup 100 --tilt --rebalance-every 1000
   grep -o '"ticks_per_s": [0-9.]*\|"particles_conserved": [a-z]*\|"neighbour_rebuilds": [0-9]*' gpurun_out/r06_soak_$n.txt | tr '\n' ' '; echo " <- ranks $ranks graph $g spec $sp"
 done; done; done
 for rep in 1 2 3; do
   n=$((n+1))
-  step 300 gpurun_out/r06_soak_$n.txt $H --ranks 4 $B --steps 12000 --warmup 100 --rebalance-every 1500
+  step 300 gpurun_out/r06_soak_$n.txt $H --ranks 4 $B --lean-spec ${SOAK_LONG_SPEC:-2} --steps 12000 --warmup 100 --rebalance-every 1500
   grep -o '"ticks_per_s": [0-9.]*\|"particles_conserved": [a-z]*\|"rebalanced": [0-9]*' gpurun_out/r06_soak_$n.txt | tr '\n' ' '; echo " <- 4 ranks, re-balancing, rep $rep"
 done
 for stall in 1:300:3 2:800:5 0:150:2; do
