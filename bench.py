@@ -821,7 +821,9 @@ def slab_overhead(sph, out):
         return {"timesteps_per_s": round(d["ticks_per_s"], 2), "window_timesteps_per_s": d.get("window_ticks_per_s"), "host": d["host"],
                 "rebuilds_per_step_whole_run": round(d["neighbour_rebuilds"] / max(warmup + windows * steps, 1), 4)}
 
-    variants = [("lean", "sph_slab_steps, speculative (the C host's default): 4 kernels per step — books | density with the criterion's jobs | gate | force —, graphs of up to 16 steps, no neighbour", []),
+    variants = [("lean", "sph_slab_steps as the C host runs them by default (--lean-spec 2): the FUSED speculative lean step, 3 kernels per step — density with the slab head's "
+                         "work and the criterion's jobs in its launch | gate | force —, graphs of up to 16 steps, no neighbour", []),
+                ("lean_spec4", "the speculative lean step as four launches (--lean-spec 1: head | density with the criterion's jobs | gate | force)", ["--lean-spec", "1"]),
                 ("lean_plain", "the plain lean step (--lean-spec 0: the criterion's boxes in the head kernel, no verification), graphs of up to 16 steps", ["--lean-spec", "0"]),
                 ("three_call", "the three-call step: 6 kernels, no neighbour", ["--lean", "0"]),
                 ("three_call_rccl_selfcomm", "three-call + the step's RCCL calls (all-reduce, grouped send / receive) to the rank itself",
@@ -863,14 +865,14 @@ def slab_overhead(sph, out):
         size = {"n_fluid": r1["n_fluid"], "window": [wu, st_, wn], "sph_step_timesteps_per_s": round(r1["steps_per_s"], 2),
                 "sph_step_window_timesteps_per_s": r1["window_steps_per_s"], "sph_step_rebuilds_per_step_whole_run": round(r1["rebuilds"] / max(total + 5, 1), 4),
                 "sph_step_window_rebuilds_per_step": r1["window_rebuilds_per_step"]}
-        for key, what, extra in variants[:3]:
+        for key, what, extra in variants[:4]:
             d = c_host("cfg4slab", wu, st_, wn, True, extra)
             size[key] = dict(d, what=what, vs_sph_step=round(d["timesteps_per_s"] / r1["steps_per_s"], 4))
             log("slab_overhead 4M developed %s: %s" % (key, size[key]))
         t32 = next((e["timesteps_per_s"] for e in out.get("also", []) if e.get("cache_key") == keyd), None)
         if t32:
             size["cfg4_one_gpu_timesteps_per_s"] = t32
-            size["strong_scaling_upper_bound_8_gpus"] = {k: round(size[k]["timesteps_per_s"] / t32, 2) for k, _w, _e in variants[:3]}
+            size["strong_scaling_upper_bound_8_gpus"] = {k: round(size[k]["timesteps_per_s"] / t32, 2) for k, _w, _e in variants[:4]}
             size["strong_scaling_upper_bound_8_gpus"]["sph_step_on_the_slab"] = round(r1["steps_per_s"] / t32, 2)
         res["sizes"]["4M developed (the same tank, steps %d-%d: the lattice has fallen)" % (wu, total)] = size
     except Exception as e_:      # (reported, never raised)

@@ -53,10 +53,13 @@
  * update message written by the force pass of the step before and everything between the ranks inside those kernels) where that is
  * possible: the peer transport, or a slab without neighbours, and the device this rank's alone (or --one-launch-wgs N: ranks that
  * share a device cap the grids of their one-launch kernels so that all of them stay resident — tests).  0: the three-call step.
- * --lean-spec 1|0 (default 1, round 6): the SPECULATIVE lean step (sph_slab_set_speculative): the rebuild criterion — boxes, verification,
+ * --lean-spec 2|1|0 (default 2, round 6): the SPECULATIVE lean step (sph_slab_set_speculative): the rebuild criterion — boxes, verification,
  * list repair — inside the launch of a speculative density pass, as in sph_step; the word goes round in the gate kernel.  One slab of
  * 2 M particles, five windows of 1000 steps of the dam break: 8 759 against 8 172 steps/s (rebuilds 230 against 561); 4 M developed: 4 195
- * against 3 098; 4 M at rest: 6 528 against 6 581.  0: the plain lean step (the criterion's boxes in the head kernel, no verification).
+ * against 3 098; 4 M at rest: 6 528 against 6 581.  2: its FUSED form — the head kernel's work (books, push of the update, wait for the
+ * neighbours', ghost update) by the first workgroups of the density launch, ghost-staging tiles wait for them: three launches per step as
+ * sph_step (2 M: 9 140 against 9 000 for the four-launch form, the first window 11 509 against 11 157; 4 M at rest 6 947 against 6 833).
+ * 0: the plain lean step (the criterion's boxes in the head kernel, no verification).
  * --lean-graph 1|0 (default 1, round 6): the lean steps between two things the HOST does (window boundaries, console lines, re-balancing)
  * go to the library as ONE call per run of steps (sph_slab_steps: up to 16 steps per captured graph, their gravity samples in a device
  * array, step number and buffer parity taken from the device); 0: sph_slab_step, one call of four launches per step.
@@ -780,7 +783,7 @@ int main(int argc, char **argv) {
     int rebalance_every = 0, capacity = 0, console = 0, selfcomm = 0, xside = 2, breakdown = 0, halo_capacity = -1;
     int repair_opt = -1;                        /* --repair -1 (default: from 4 000 000 particles per slab on) | 0 | 1: sph_set_list_repair */
     int verify_opt = -1;                        /* --verify -1 (default: the library's — slab contexts verify only when asked: 1) | 0 | 1: sph_set_verification */
-    int lean_graph_opt = 1, lean_spec_opt = 1;
+    int lean_graph_opt = 1, lean_spec_opt = 2;
     int lean_opt = -1, one_launch_wgs = 0;      /* --lean auto (-1) | 0 | 1; --one-launch-wgs N: cap of the one-launch kernels' grid (ranks that share a device) */
     float skin = -1;
     const char *scene_name = "dam", *idfile = NULL, *shm_name = NULL, *frame_file = NULL, *state_file = NULL, *accel_file = NULL, *before_file = NULL, *before_accel_file = NULL;
