@@ -253,14 +253,15 @@ def test_c_host_lean_step_with_a_rank_held_up_between_its_launches(sph, tmp_path
     arrive'.)  $SPH_TEST_STALL_AFTER_HEAD holds rank 1's host for 300 us between the head kernel and the rest of every third step:
     the run ends cleanly and with the bits of the run nobody held up — the message of step t is still in the buffer of its parity.
     (Round 6: the hook is compiled into the TEST build of the library only — `make stress`, -DSPH_TEST_HOOKS — and both runs go through
-    host/slab_sph_fluid_stress, the C host linked against it; sph_slab_step one call per step: --lean-graph 0.)"""
+    host/slab_sph_fluid_stress, the C host linked against it; sph_slab_step one call per step: --lean-graph 0; the four-launch speculative
+    form, --lean-spec 1: the fused form has no host between a step's launches to hold up.)"""
     if not os.path.exists(HOST_STRESS):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "pi-sph-fluid_amd"), "stress"])
     states = []
     for stall in (None, "1:300:3"):
         state = tmp_path / ("state_%s.bin" % (stall is not None))
         r, out, rec = _run_host(["--ranks", 3, "--transport", "peer", "--lean", 1, "--one-launch-wgs", 256, "--block", 600, 150, 90, 20,
-                                 "--velocity", 5, 0, "--steps", 200, "--warmup", 40, "--deterministic", "--lean-graph", 0, "--dump-state", state],
+                                 "--velocity", 5, 0, "--steps", 200, "--warmup", 40, "--deterministic", "--lean-graph", 0, "--lean-spec", 1, "--dump-state", state],
                                 env=None if stall is None else {"SPH_TEST_STALL_AFTER_HEAD": stall}, host=HOST_STRESS)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         assert rec["particles_conserved"] is True and 0 < rec["neighbour_rebuilds"] < 200 and "lean step" in rec["host"]

@@ -6,7 +6,7 @@
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out /tmp/eqwait
 make -s -C pi-sph-fluid_amd stress
-cmd="pi-sph-fluid_amd/host/slab_sph_fluid_stress --lean-graph 0 --ranks 3 --transport peer --lean 1 --one-launch-wgs 256 --block 600 150 90 20 --velocity 5 0 --steps 200 --warmup 40 --deterministic"
+cmd="pi-sph-fluid_amd/host/slab_sph_fluid_stress --lean-graph 0 --lean-spec 1 --ranks 3 --transport peer --lean 1 --one-launch-wgs 256 --block 600 150 90 20 --velocity 5 0 --steps 200 --warmup 40 --deterministic"
 for v in asbuilt eqwait; do
     if [ $v = eqwait ]; then
         [ -f pi-sph-fluid_amd/csrc/libsph_hip_eqwait.so ] || continue

@@ -18,6 +18,6 @@ for rep in 1 2 3; do
 done
 for stall in 1:300:3 2:800:5 0:150:2; do
   n=$((n+1))
-  SPH_TEST_STALL_AFTER_HEAD=$stall step 300 gpurun_out/r06_soak_$n.txt $HS --ranks 4 $B --lean-graph 0 --steps 3000 --warmup 100
+  SPH_TEST_STALL_AFTER_HEAD=$stall step 300 gpurun_out/r06_soak_$n.txt $HS --ranks 4 $B --lean-graph 0 --lean-spec 1 --steps 3000 --warmup 100
   grep -o '"ticks_per_s": [0-9.]*\|"particles_conserved": [a-z]*' gpurun_out/r06_soak_$n.txt | tr '\n' ' '; echo " <- 4 ranks, stall $stall"
 done
