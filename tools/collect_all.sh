@@ -36,9 +36,9 @@ if [ "$PART" != a ]; then
 # one slab of 2 000 000 particles through the C host, in-process (one rank: the host neither forks nor execs): the lean step's four
 # kernels and the three-call step's six, steps 200-1200 of the dam break
 cd /tmp && export TMPDIR=/tmp
-# (round 6: lean = the speculative lean step, the C host's default; lean_plain = --lean-spec 0)
-for v in lean lean_plain three_call; do
-    opts="--lean 1"; [ $v = lean_plain ] && opts="--lean 1 --lean-spec 0"; [ $v = three_call ] && opts="--lean 0"
+# (round 6: lean = the fused speculative lean step, the C host's default; lean_spec4 = --lean-spec 1, four launches; lean_plain = --lean-spec 0)
+for v in lean lean_spec4 lean_plain three_call; do
+    opts="--lean 1"; [ $v = lean_spec4 ] && opts="--lean 1 --lean-spec 1"; [ $v = lean_plain ] && opts="--lean 1 --lean-spec 0"; [ $v = three_call ] && opts="--lean 0"
     mkdir -p "$root/gpurun_out/prof_${R}_slab1_$v"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_${R}_slab1_$v/trace" -o trace -- \
         "$root/pi-sph-fluid_amd/host/slab_sph_fluid" --ranks 1 --scene dam $opts --warmup 200 --steps 1000 > "$root/gpurun_out/prof_${R}_slab1_$v/trace.log" 2>&1
