@@ -1550,7 +1550,7 @@ int feed_gravity_ring(sph_ctx *ctx, uint32_t first, const float *gravity_xy, int
     const int slot = ctx->gseq_slot++ % GSEQ_SLOTS;
     if (ctx->gseq_used[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->gseq_ev[slot]));
     float *h = ctx->h_gseq + (size_t)slot * 2 * MULTI_STEPS;
-    static_assert(GRAV_RING <= MULTI_STEPS, "the pinned staging slots hold a whole ring");
+    static_assert(GRAV_RING == MULTI_STEPS, "a run of MULTI_STEPS steps fills the ring once, and a pinned staging slot holds a whole ring");
     memcpy(h, want, sizeof want);
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_gring, h, sizeof want, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->gseq_ev[slot], ctx->stream));
@@ -1820,6 +1820,8 @@ int sph_slab_set_buffers(sph_ctx *ctx, void *send_left, void *send_right, void *
         HIPCHK(ctx, hipMemsetAsync(ctx->a.recv[k], 0, ctx->halo_bytes, ctx->stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graph(ctx);      // (the buffers are arguments of captured launches)
+    if (ctx->lean_spec == 2) return upload_fuse(ctx);      // (... and fields of the fused step's device record)
     return SPH_OK;
 }
 
