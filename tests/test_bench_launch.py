@@ -244,3 +244,15 @@ def test_six_ranks_rehearsal_weak_and_strong_legs(sph, tmp_path):
     # developed: this run's window differs from the cached one -> rank 0 measured the one-GPU rate itself, on that window
     assert strong["developed"]["window"] == [300, 40, 3] and strong["developed"]["reference"].startswith("measured in this run")
     assert strong["developed"]["one_gpu_timesteps_per_s"] != legs["cfg4_developed"]["timesteps_per_s"]
+
+
+@pytest.mark.gpu
+def test_box_calibration_is_plausible(sph):
+    """sph_box_calibrate (include/sph_diag.h; the `box` key of the bench line): what THIS box delivers to a streaming copy and to a
+    saturated v_fma_f32 stream — between a third of the HBM specification and the specification, between 2 and 4 SIMD-cycles per
+    wave-instruction at the nominal clock, a shader clock between 1.2 and 2.6 GHz (MI355X: 2.4 GHz peak) — and repeatable to 10 %."""
+    b = sph.box_calibrate(0, 3)
+    assert 2500.0 < b["copy_gbs"] < 8000.0, b
+    assert 1.9 < b["valu_cycles"] < 4.0, b
+    assert b["clock_ghz"] is None or 1.2 < b["clock_ghz"] < 2.6, b
+    assert max(b["copy_gbs_runs"]) < 1.1 * min(b["copy_gbs_runs"]) and max(b["valu_cycles_runs"]) < 1.1 * min(b["valu_cycles_runs"]), b
