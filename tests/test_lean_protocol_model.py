@@ -9,6 +9,8 @@ launches — a rank may sit between its head kernel and the rest of its step for
     rounds 3-5 shipped does not (the defect tests/test_slab_c_host.py::test_c_host_lean_step_with_a_rank_held_up_between_its_launches
     reproduces on the GPU),
   * all ranks take the rebuild branch in the same steps.
+Round 6: the same for the speculative lean step (run_model_speculative), in which the wait for the neighbours' update comes BEFORE
+the word goes round.
 No GPU, no library: the CPU suite."""
 import random
 import threading
@@ -24,7 +26,9 @@ class Block:      # what one rank exports
         self.slots = [[0] * n, [0] * n]                           # [parity][sender] = step << 2 | word
 
 
-def run_model(n_ranks, steps, wait_at_least, seed, stall_rank=1, timeout=20.0):
+def run_model(n_ranks, steps, wait_at_least, seed, stall_rank=1, timeout=20.0, speculative=False):
+    if speculative:
+        return run_model_speculative(n_ranks, steps, seed, stall_rank, timeout)
     blocks = [Block(n_ranks) for _ in range(n_ranks)]
     errors, rebuilt = [], [[] for _ in range(n_ranks)]
     deadline = time.time() + timeout
@@ -91,6 +95,88 @@ def run_model(n_ranks, steps, wait_at_least, seed, stall_rank=1, timeout=20.0):
     for th in threads:
         th.join()
     return errors, rebuilt
+
+
+def run_model_speculative(n_ranks, steps, seed, stall_rank=1, timeout=20.0):
+    """The speculative lean step (round 6; sph_slab_set_speculative, both forms — four launches or the head fused into the density
+    launch: the same order between the ranks): per step  push my update + wait for the neighbours' + unpack  |  density (whose jobs
+    produce this rank's word)  |  gate: exchange the word, then nothing — or push my records, wait for theirs, ingest  |  force.
+    The wait for the neighbours' update now comes BEFORE the word goes round, the records still after: the update of step t and the
+    records of step t share the buffer of parity t, and nobody may write records over an update its neighbour has not unpacked yet."""
+    blocks = [Block(n_ranks) for _ in range(n_ranks)]
+    errors, rebuilt = [], [[] for _ in range(n_ranks)]
+    deadline = time.time() + timeout
+    words = [[1 if random.Random(7919 * r + 31 * seed + t).random() < 0.15 else 0 for t in range(steps + 2)] for r in range(n_ranks)]
+
+    def wait(pred, what):
+        while not pred():
+            if time.time() > deadline:
+                raise TimeoutError(what)
+            time.sleep(0)
+
+    def rank(me):
+        rng = random.Random(seed * 131 + me)
+        left, right = (me - 1 if me > 0 else None), (me + 1 if me < n_ranks - 1 else None)
+
+        def hold(p, most):
+            if me == stall_rank and rng.random() < 0.3:
+                time.sleep(0.002)
+            elif rng.random() < p:
+                time.sleep(rng.random() * most)
+
+        try:
+            for t in range(1, steps + 1):
+                par = t & 1
+                # head (or the first workgroups of the density launch): push this step's update, raise the neighbours' flags ...
+                for nb, side_there in ((left, 1), (right, 0)):
+                    if nb is not None:
+                        blocks[nb].recv[side_there][par] = ("update", t, me)
+                        blocks[nb].flag[side_there] = 2 * t
+                # ... wait for theirs ("at least": a neighbour may be a launch ahead), unpack
+                for nb, side in ((left, 0), (right, 1)):
+                    if nb is not None:
+                        wait(lambda side=side: blocks[me].flag[side] >= 2 * t, "rank %d step %d: update flag, side %d" % (me, t, side))
+                        got = blocks[me].recv[side][par]
+                        if got != ("update", t, nb):
+                            errors.append((me, t, side, got))
+                hold(0.3, 0.0003)      # the density launch; a rank may be held up anywhere
+                # gate: the MAX of the word over the ranks
+                for q in range(n_ranks):
+                    blocks[q].slots[par][me] = (t << 2) | words[me][t]
+                for q in range(n_ranks):
+                    wait(lambda q=q: blocks[me].slots[par][q] >> 2 == t, "rank %d step %d: word of rank %d" % (me, t, q))
+                word = max(blocks[me].slots[par][q] & 3 for q in range(n_ranks))
+                hold(0.3, 0.0003)
+                if word != 0:      # rebuild: records to the neighbours (over the update of this parity), flags 2 t + 1, wait for mine, ingest
+                    rebuilt[me].append(t)
+                    for nb, side_there in ((left, 1), (right, 0)):
+                        if nb is not None:
+                            blocks[nb].recv[side_there][par] = ("records", t, me)
+                            blocks[nb].flag[side_there] = 2 * t + 1
+                    for nb, side in ((left, 0), (right, 1)):
+                        if nb is not None:
+                            wait(lambda side=side: blocks[me].flag[side] >= 2 * t + 1, "rank %d step %d: records flag, side %d" % (me, t, side))
+                            got = blocks[me].recv[side][par]
+                            if got != ("records", t, nb):
+                                errors.append((me, t, side, got))
+                hold(0.3, 0.0002)      # force
+        except TimeoutError as e:
+            errors.append(("timeout", str(e)))
+
+    threads = [threading.Thread(target=rank, args=(r,)) for r in range(n_ranks)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    return errors, rebuilt
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3, 4])
+def test_speculative_step_every_rank_reads_the_message_of_its_own_step(n_ranks):
+    for seed in range(3):
+        errors, rebuilt = run_model(n_ranks, 240, True, seed, speculative=True)
+        assert not errors, errors[:3]
+        assert all(rb == rebuilt[0] for rb in rebuilt) and len(rebuilt[0]) > 10      # the same rebuild steps everywhere
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3, 4])
