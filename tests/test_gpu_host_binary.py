@@ -67,8 +67,12 @@ def test_default_scene_4000_steps_aggregates(sph, tmp_path):
     assert 4.0 <= worst_speed <= 8.0                                     # the drop hits the floor at ~4.3 m/s and splashes
     rho_err = [float(m.group(3)) for m in stats]
     # the author's health criterion: ~1 % (:16, :662).  The statistic is the maximum over the particles at one instant of a chaotic
-    # splash: the reference's own two builds give 0.43 % (-O2) and 0.16 % (-Ofast) as their worst of the nine lines, this trajectory
-    # (round 5's arithmetic: 1.22 % in ONE line, 0.35 % in the next worst) another: at most one line may spike, none beyond 2 %
+    # splash, and this deterministic run is ONE trajectory of it: the reference's own arithmetic from initial positions perturbed by
+    # +-4 ulp gives a worst line between 0.10 and 1.36 % (oracle/rho_gate_chaos.py, 600 runs: median 0.25 %, 4 runs beyond 1 %, the
+    # second-worst line never beyond 0.50 %), so one trajectory is held to the reference's RANGE — at most one line may spike, none
+    # beyond 2 % — and the arithmetic itself to the reference's DISTRIBUTION by tests/test_gpu_health.py (24 perturbed runs; round 6,
+    # with the bisect the round-5 advisor asked for: IEEE divisions in the EOS, skin_min 0.12 and the deterministic order all give the
+    # same distribution, tools/rho_gate_gpu.py)
     assert max(rho_err) < 2.0 and sorted(rho_err)[-2] < 1.0, rho_err
     ref = g["state_4000"]
     assert abs(st[:, 1].mean() - ref[:, 1].mean()) <= 0.05 * ref[:, 1].mean()
