@@ -729,6 +729,7 @@ def run_c_host(sph, args):
         # at rest and developed, each against the one-GPU rate on its own window
         "scaling_detail": {"weak": weak, "strong": strong},
         "cpu_baseline": cached_cpu_baseline(),      # measured by the N = 1 run on this host (None if there was none)
+        "box": box_calibration(sph),                # what device 0 of this node delivers (after the multi-rank legs: the GPU is free)
     }
     if fallback:
         out["transport_used"] = "peer (--transport auto: the RCCL run of this bench did not complete: exit %d)" % rc
