@@ -674,7 +674,9 @@ def run_c_host(sph, args):
         peer_raw["weak"] = peer_leg(host, scene, n_ranks, args.steps, args.warmup, args.workload == "cfg4")
         if scene == "dam":
             for name, (key, wu, st_, wn) in STRONG_LEGS.items():
-                peer_raw[name] = peer_leg(host, "cfg4", n_ranks, st_, wu, True, windows=wn)
+                # (a transport that did not get through the small leg is not given two long ones to time out in: 3 minutes each)
+                peer_raw[name] = (peer_leg(host, "cfg4", n_ranks, st_, wu, True, windows=wn) if peer_raw["weak"].get("status") == "ok"
+                                  else {"status": "skipped: the weak leg over this transport did not complete (%s)" % peer_raw["weak"].get("status")})
     # --transport best: the faster of two runs that agree is the line's value (the other stays in the line)
     chosen, rccl_weak_raw = None, None
     if best and transport == "rccl" and n_ranks > 1 and "weak" in peer_raw:
